@@ -1,0 +1,138 @@
+"""ORACLE (test infrastructure only) -- CPU restatement of the I3D-ResNet50 forward.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import
+this module; the shipped path (`anomaly_detection_on_video_amd.i3d`) never does.
+
+This is a *functional* restatement (no module tree) of the reference's arithmetic in plain
+fp32 torch CPU ops, driven directly by a state dict with the reference's key layout:
+
+    stem      conv1 k(5,7,7) s2 p(2,3,3) -> bn1 -> relu        /root/reference/src/i3d.py:202-211, 303-305
+    maxpool1  k(2,3,3) s2 p0                                   src/i3d.py:212-214, 306
+    layer1..4 Bottleneck x [3,4,6,3]                           src/i3d.py:220-243, 308-312
+      conv1 k(1+2*tc,1,1) p(tc,0,0) -> bn -> relu              src/i3d.py:67-75, 101-103
+      conv2 k(1,3,3) s(1,s,s) p(0,1,1) -> bn -> relu           src/i3d.py:76-84, 105-107
+      conv3 k1 x4 -> bn ; (+ downsample(x) = conv k1 s(1,s,s) + bn) ; += ; relu   src/i3d.py:85-88, 109-116, 262-272
+    maxpool2  k(2,1,1) s(2,1,1) between layer1 and layer2      src/i3d.py:215-217, 309
+    avgpool   AdaptiveAvgPool3d(1)                             src/i3d.py:244, 314
+
+Parity pinning: `tests/golden/make_golden.py` runs the *reference's own* `I3Res50`
+(imported from /root/reference with the absent third-party `pytorchvideo` import stubbed)
+on the same deterministic weights/inputs and commits its outputs under `tests/golden/`;
+`tests/test_oracle_golden.py` checks this restatement against those vectors.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5  # nn.BatchNorm3d default, src/i3d.py:75
+
+# (name, planes, spatial stride, temporal-conv flags)  src/i3d.py:220-243
+STAGES: List[Tuple[str, int, int, List[int]]] = [
+    ("layer1", 64, 1, [1, 1, 1]),
+    ("layer2", 128, 2, [1, 0, 1, 0]),
+    ("layer3", 256, 2, [1, 0, 1, 0, 1, 0]),
+    ("layer4", 512, 2, [0, 1, 0]),
+]
+
+
+def _bn(x: torch.Tensor, sd: Dict[str, torch.Tensor], p: str) -> torch.Tensor:
+    return F.batch_norm(
+        x, sd[f"{p}.running_mean"], sd[f"{p}.running_var"], sd[f"{p}.weight"], sd[f"{p}.bias"],
+        training=False, eps=BN_EPS,
+    )
+
+
+def bottleneck(x: torch.Tensor, sd: Dict[str, torch.Tensor], p: str, stride: int, temp_conv: int, has_ds: bool) -> torch.Tensor:
+    out = F.conv3d(x, sd[f"{p}.conv1.weight"], None, stride=1, padding=(temp_conv, 0, 0))
+    out = F.relu(_bn(out, sd, f"{p}.bn1"))
+    out = F.conv3d(out, sd[f"{p}.conv2.weight"], None, stride=(1, stride, stride), padding=(0, 1, 1))
+    out = F.relu(_bn(out, sd, f"{p}.bn2"))
+    out = F.conv3d(out, sd[f"{p}.conv3.weight"], None)
+    out = _bn(out, sd, f"{p}.bn3")
+    if has_ds:
+        res = F.conv3d(x, sd[f"{p}.downsample.0.weight"], None, stride=(1, stride, stride))
+        res = _bn(res, sd, f"{p}.downsample.1")
+    else:
+        res = x
+    return F.relu(out + res)
+
+
+@torch.no_grad()
+def i3d_forward(
+    x: torch.Tensor,
+    sd: Dict[str, torch.Tensor],
+    tap: Optional[Callable[[str, torch.Tensor], None]] = None,
+) -> torch.Tensor:
+    """(B,3,T,H,W) fp32 -> (B,2048,1,1,1).  `tap(name, tensor)` sees every stage output."""
+    t = tap or (lambda n, v: None)
+    x = F.conv3d(x, sd["conv1.weight"], None, stride=(2, 2, 2), padding=(2, 3, 3))
+    x = F.relu(_bn(x, sd, "bn1"))
+    t("stem", x)
+    x = F.max_pool3d(x, kernel_size=(2, 3, 3), stride=(2, 2, 2))
+    t("maxpool1", x)
+    for name, _planes, stride, temps in STAGES:
+        for i, tc in enumerate(temps):
+            x = bottleneck(x, sd, f"{name}.{i}", stride if i == 0 else 1, tc, i == 0)
+            t(f"{name}.{i}", x)
+        t(name, x)
+        if name == "layer1":
+            x = F.max_pool3d(x, kernel_size=(2, 1, 1), stride=(2, 1, 1))
+            t("maxpool2", x)
+    x = F.adaptive_avg_pool3d(x, 1)
+    t("avgpool", x)
+    return x
+
+
+@torch.no_grad()
+def conv_bn_act(
+    x: torch.Tensor,
+    w: torch.Tensor,
+    gamma: torch.Tensor,
+    beta: torch.Tensor,
+    mean: torch.Tensor,
+    var: torch.Tensor,
+    stride: Tuple[int, int, int],
+    padding: Tuple[int, int, int],
+    residual: Optional[torch.Tensor] = None,
+    relu: bool = True,
+) -> torch.Tensor:
+    """One conv -> eval-BN (-> +residual) (-> relu) unit, the granularity of the HIP kernels."""
+    y = F.conv3d(x, w, None, stride=stride, padding=padding)
+    y = F.batch_norm(y, mean, var, gamma, beta, training=False, eps=BN_EPS)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
+def conv_macs(in_shape: Tuple[int, int, int, int, int] = (1, 3, 16, 224, 224)) -> int:
+    """Multiply-accumulates of all 53 convs for one forward (16.415 G per crop-clip at 16x224^2)."""
+    b, c, t, h, w = in_shape
+    total = 0
+
+    def conv(cin, cout, k, s, p, t, h, w):
+        nonlocal total
+        to = (t + 2 * p[0] - k[0]) // s[0] + 1
+        ho = (h + 2 * p[1] - k[1]) // s[1] + 1
+        wo = (w + 2 * p[2] - k[2]) // s[2] + 1
+        total += b * cout * to * ho * wo * cin * k[0] * k[1] * k[2]
+        return to, ho, wo
+
+    t, h, w = conv(3, 64, (5, 7, 7), (2, 2, 2), (2, 3, 3), t, h, w)
+    t, h, w = (t - 2) // 2 + 1, (h - 3) // 2 + 1, (w - 3) // 2 + 1
+    inpl = 64
+    for name, planes, stride, temps in STAGES:
+        for i, tc in enumerate(temps):
+            s = stride if i == 0 else 1
+            conv(inpl, planes, (1 + 2 * tc, 1, 1), (1, 1, 1), (tc, 0, 0), t, h, w)
+            t2, h2, w2 = conv(planes, planes, (1, 3, 3), (1, s, s), (0, 1, 1), t, h, w)
+            conv(planes, planes * 4, (1, 1, 1), (1, 1, 1), (0, 0, 0), t2, h2, w2)
+            if i == 0:
+                conv(inpl, planes * 4, (1, 1, 1), (1, s, s), (0, 0, 0), t, h, w)
+            t, h, w = t2, h2, w2
+            inpl = planes * 4
+        if name == "layer1":
+            t = (t - 2) // 2 + 1
+    return total
