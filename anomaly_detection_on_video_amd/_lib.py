@@ -1,0 +1,121 @@
+"""ctypes binding of libadvhip.so (include/advhip.h).
+
+The shared library is built in-tree by `anomaly_detection_on_video_amd.build` (hipcc,
+--offload-arch=gfx950) and is the ONLY compute path of this package for the ops it covers:
+there is no eager / CPU fallback.  If the library is missing, or a tensor is not on a GPU, the
+callers raise -- loudly -- instead of silently computing somewhere else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libadvhip.so")
+
+ALGO_AUTO = 0
+ALGO_IGEMM_128x128 = 1
+ALGO_IGEMM_128x64 = 2
+ALGO_IGEMM_64x64 = 3
+ALGO_IGEMM_64x128 = 4
+ALGO_STEM = 16
+
+
+class HipExtensionError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "B", "Cin", "T", "H", "W", "Cout", "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw",
+        "relu", "algo", "reserved")]
+
+
+_P = C.c_void_p
+_I = C.c_int32
+_L = C.c_int64
+
+# name -> (restype, argtypes); every symbol include/advhip.h declares
+SIGNATURES = {
+    "advhip_abi_version": (C.c_int, []),
+    "advhip_last_error": (C.c_char_p, []),
+    "advhip_target_arch": (C.c_char_p, []),
+    "advhip_conv3d_out_dims": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "advhip_conv3d_packed_rows": (C.c_int, [C.POINTER(ConvDesc)]),
+    "advhip_conv3d_pack_weight_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P]),
+    "advhip_conv3d_build_ktab": (C.c_int, [C.POINTER(ConvDesc), _P, _P]),
+    "advhip_bn_fold_f32": (C.c_int, [_P, _P, _P, _P, C.c_float, _I, _P, _P, _P]),
+    "advhip_conv3d_bn_act_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "advhip_maxpool3d_f32": (C.c_int, [_P, _P] + [_I] * 11 + [_P]),
+    "advhip_global_avgpool_f32": (C.c_int, [_P, _P, _L, _I, _P]),
+    "advhip_mil_magnitude_f32": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "advhip_mil_topk_select_f32": (C.c_int, [_P] * 7 + [_I] * 5 + [_P]),
+    "advhip_mil_topk_select_bwd_f32": (C.c_int, [_P] * 5 + [_I] * 5 + [_P]),
+    "advhip_mil_magnitude_bwd_f32": (C.c_int, [_P] * 5 + [_I] * 4 + [_P]),
+    "advhip_mgfn_loss_ws_floats": (_L, [_I, _I, _I]),
+    "advhip_mgfn_loss_fwd_f32": (C.c_int, [_P] * 9 + [_I] * 5 + [_P]),
+    "advhip_mgfn_loss_bwd_f32": (C.c_int, [_P] * 14 + [_I] * 5 + [_P]),
+    "advhip_segment_features_f32": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    "advhip_add_magnitude_f32": (C.c_int, [_P, _P, _L, _I, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load(path: Optional[str] = None) -> C.CDLL:
+    """dlopen the C-ABI library and bind every declared symbol (raises if one is missing)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise HipExtensionError(
+            f"{p} not found: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or "
+            "`python -m anomaly_detection_on_video_amd.build`). There is no CPU fallback."
+        )
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise HipExtensionError(f"{p} does not export {name}; rebuild the extension") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.advhip_abi_version() != 1:
+        raise HipExtensionError(f"{p}: ABI version {lib.advhip_abi_version()} != 1; rebuild the extension")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "advhip") -> None:
+    if rc != 0:
+        msg = load().advhip_last_error().decode("utf-8", "replace")
+        raise HipExtensionError(f"{what} failed (code {rc}): {msg}")
+
+
+def require_gpu(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise HipExtensionError(
+                "this op runs only as a HIP kernel on an AMD GPU; got a tensor on "
+                f"'{t.device}'. Move the module and its inputs to cuda (there is no CPU fallback)."
+            )
+        if t.dtype != torch.float32 and t.dtype != torch.int64 and t.dtype != torch.int32:
+            raise HipExtensionError(f"unsupported dtype {t.dtype}; the kernels compute in fp32")
+        if not t.is_contiguous():
+            raise HipExtensionError("HIP kernels need contiguous tensors")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,75 @@
+// Pooling kernels of the I3D backbone (HBM-bound, NCDHW fp32).
+//   maxpool3d      : nn.MaxPool3d, padding 0, floor mode   (/root/reference/src/i3d.py:212-217, 306, 309)
+//   global_avgpool : nn.AdaptiveAvgPool3d((1,1,1))         (/root/reference/src/i3d.py:244, 314)
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+
+namespace advhip {
+
+// One thread per output element, consecutive threads along W (coalesced stores; the window
+// reads of neighbouring threads overlap and are served by L1/L2).
+__global__ void maxpool3d_kernel(const float* __restrict__ x, float* __restrict__ y, int T, int H, int W, int To,
+                                 int Ho, int Wo, int kt, int kh, int kw, int st, int sh, int sw, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int wo = (int)(i % Wo);
+    long long r = i / Wo;
+    const int ho = (int)(r % Ho);
+    r /= Ho;
+    const int to = (int)(r % To);
+    const long long bc = r / To;
+    const float* p = x + ((bc * T + (long long)to * st) * H + (long long)ho * sh) * W + (long long)wo * sw;
+    float m = -INFINITY;
+    for (int a = 0; a < kt; ++a)
+      for (int b = 0; b < kh; ++b)
+        for (int c = 0; c < kw; ++c) {
+          const float v = p[((long long)a * H + b) * W + c];
+          // torch's max pooling propagates NaN
+          m = (v > m || v != v) ? v : m;
+        }
+    y[i] = m;
+  }
+}
+
+// One wavefront per row: lanes stride the row, then a 64-wide shuffle reduction.
+__global__ void global_avgpool_kernel(const float* __restrict__ x, float* __restrict__ y, long long rows, int n) {
+  const int lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = x + row * n;
+  float s = 0.f;
+  for (int i = lane; i < n; i += 64) s += p[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) y[row] = s / (float)n;
+}
+
+}  // namespace advhip
+
+using namespace advhip;
+
+extern "C" int advhip_maxpool3d_f32(const float* x, float* y, int32_t B, int32_t C, int32_t T, int32_t H, int32_t W,
+                                    int32_t kt, int32_t kh, int32_t kw, int32_t st, int32_t sh, int32_t sw,
+                                    void* stream) {
+  ADVHIP_REQUIRE(x && y, "maxpool3d: null pointer");
+  ADVHIP_REQUIRE(B > 0 && C > 0 && T >= kt && H >= kh && W >= kw && kt > 0 && kh > 0 && kw > 0 && st > 0 && sh > 0 && sw > 0,
+                 "maxpool3d: bad shape (B=%d C=%d T=%d H=%d W=%d k=%d,%d,%d s=%d,%d,%d)", B, C, T, H, W, kt, kh, kw, st, sh, sw);
+  const int To = (T - kt) / st + 1, Ho = (H - kh) / sh + 1, Wo = (W - kw) / sw + 1;
+  const long long total = (long long)B * C * To * Ho * Wo;
+  const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(maxpool3d_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, T, H, W, To, Ho, Wo, kt, kh,
+                     kw, st, sh, sw, total);
+  return check_launch("maxpool3d");
+}
+
+extern "C" int advhip_global_avgpool_f32(const float* x, float* y, int64_t rows, int32_t n, void* stream) {
+  ADVHIP_REQUIRE(x && y && rows > 0 && n > 0, "global_avgpool: bad arguments");
+  const int wpb = 4;  // waves per block
+  const long long grid = (rows + wpb - 1) / wpb;
+  ADVHIP_REQUIRE(grid < (1ll << 31), "global_avgpool: too many rows");
+  hipLaunchKernelGGL(global_avgpool_kernel, dim3((unsigned)grid), dim3(64 * wpb), 0, (hipStream_t)stream, x, y,
+                     (long long)rows, n);
+  return check_launch("global_avgpool");
+}

@@ -1,0 +1,245 @@
+"""I3D-ResNet50 feature extractor executed by hand-written gfx950 HIP kernels.
+
+Drop-in for the reference's `src/i3d.py`: same class names (`I3Res50`, `Bottleneck`), constructor
+arguments, state-dict keys (conv1.weight, bn1.*, layerL.B.{conv1,bn1,conv2,bn2,conv3,bn3}.*,
+layerL.0.downsample.{0,1}.*) and `forward((B,3,T,H,W)) -> (B,2048,1,1,1)`
+(/root/reference/src/i3d.py:60-121, 198-318, 332-364).
+
+The nn.Conv3d / nn.BatchNorm3d children are *parameter holders only* (they give the reference's
+state-dict layout, `.cuda()`, `load_state_dict`, ...).  Their `forward` is never called: the
+network is run as a flat plan of fused launches
+
+    conv3d (fp32 MFMA implicit GEMM) + folded eval-BN (+ residual) (+ ReLU)     53 launches
+    maxpool3d x2, global average pool                                            3 launches
+
+through the C ABI in include/advhip.h.  Eval-mode only (BatchNorm running statistics), no
+autograd, CUDA tensors only -- anything else raises; there is no eager fallback.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+
+repo_id = "jinmang2/test_video_fe"
+model_zoo = {
+    "i3d_8x8_r50": "I3D_8x8_R50.pyth",
+    "tushar-n-baseline": "converted_ref_i3d.pt",
+}
+
+
+class Bottleneck(nn.Module):
+    """Residual unit: (kt,1,1) conv -> (1,3,3) conv -> 1x1x1 conv x4 (+ downsample), src/i3d.py:60-121."""
+
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride, downsample, temp_conv, temp_stride, use_nl=False):
+        super().__init__()
+        if use_nl:
+            raise NotImplementedError(
+                "NonLocalBlock is dead code under the reference's only call site (use_nl=False, "
+                "src/i3d.py:219,338) and is not part of the HIP path"
+            )
+        self.conv1 = nn.Conv3d(inplanes, planes, kernel_size=(1 + temp_conv * 2, 1, 1), stride=(temp_stride, 1, 1),
+                               padding=(temp_conv, 0, 0), bias=False)
+        self.bn1 = nn.BatchNorm3d(planes)
+        self.conv2 = nn.Conv3d(planes, planes, kernel_size=(1, 3, 3), stride=(1, stride, stride), padding=(0, 1, 1), bias=False)
+        self.bn2 = nn.BatchNorm3d(planes)
+        self.conv3 = nn.Conv3d(planes, planes * 4, kernel_size=1, stride=1, padding=0, bias=False)
+        self.bn3 = nn.BatchNorm3d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+        self.nl = None
+
+    def forward(self, x):  # pragma: no cover - guarded
+        raise _lib.HipExtensionError("Bottleneck runs only inside I3Res50's fused HIP plan; call the parent model")
+
+
+class I3Res50(nn.Module):
+    def __init__(self, block=Bottleneck, layers=[3, 4, 6, 3], use_nl=False):
+        self.inplanes = 64
+        super().__init__()
+        if use_nl:
+            raise NotImplementedError("non-local blocks are outside the hot path (src/i3d.py:219)")
+        self.conv1 = nn.Conv3d(3, 64, kernel_size=(5, 7, 7), stride=(2, 2, 2), padding=(2, 3, 3), bias=False)
+        self.bn1 = nn.BatchNorm3d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool1 = nn.MaxPool3d(kernel_size=(2, 3, 3), stride=(2, 2, 2), padding=(0, 0, 0))
+        self.maxpool2 = nn.MaxPool3d(kernel_size=(2, 1, 1), stride=(2, 1, 1), padding=(0, 0, 0))
+        self.layer1 = self._make_layer(block, 64, layers[0], 1, [1, 1, 1], [1, 1, 1])
+        self.layer2 = self._make_layer(block, 128, layers[1], 2, [1, 0, 1, 0], [1, 1, 1, 1])
+        self.layer3 = self._make_layer(block, 256, layers[2], 2, [1, 0, 1, 0, 1, 0], [1, 1, 1, 1, 1, 1])
+        self.layer4 = self._make_layer(block, 512, layers[3], 2, [0, 1, 0], [1, 1, 1])
+        self.avgpool = nn.AdaptiveAvgPool3d((1, 1, 1))
+        # same initialisation as the reference (src/i3d.py:246-251)
+        for m in self.modules():
+            if isinstance(m, nn.Conv3d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out")
+            elif isinstance(m, nn.BatchNorm3d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+        self._plan: Optional[List["_Unit"]] = None
+        self._plan_stamp: Optional[Tuple] = None
+        # layer name -> ADVHIP_ALGO_* override (tuning hook)
+        self.algo_overrides: Dict[str, int] = {}
+
+    def _make_layer(self, block, planes, blocks, stride, temp_conv, temp_stride):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion or temp_stride[0] != 1:
+            downsample = nn.Sequential(
+                nn.Conv3d(self.inplanes, planes * block.expansion, kernel_size=(1, 1, 1),
+                          stride=(temp_stride[0], stride, stride), padding=(0, 0, 0), bias=False),
+                nn.BatchNorm3d(planes * block.expansion),
+            )
+        layers = [block(self.inplanes, planes, stride, downsample, temp_conv[0], temp_stride[0], False)]
+        self.inplanes = planes * block.expansion
+        for i in range(1, blocks):
+            layers.append(block(self.inplanes, planes, 1, None, temp_conv[i], temp_stride[i], False))
+        return nn.Sequential(*layers)
+
+    # ------------------------------------------------------------------ plan (load-time packing)
+    def _stamp(self) -> Tuple:
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def _pack(self, conv: nn.Conv3d, bn: nn.BatchNorm3d, name: str) -> ops.PackedConv:
+        return ops.pack_conv(conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                             conv.stride, conv.padding, name=name, algo=self.algo_overrides.get(name, _lib.ALGO_AUTO))
+
+    def prepare(self, force: bool = False) -> None:
+        """Fold BN and pack weights into the kernels' layout (once; redone if parameters change)."""
+        stamp = self._stamp()
+        if not force and self._plan is not None and stamp == self._plan_stamp:
+            return
+        dev = self.conv1.weight.device
+        if dev.type != "cuda":
+            raise _lib.HipExtensionError(
+                f"I3Res50 parameters are on '{dev}': the backbone runs only as HIP kernels on an AMD GPU "
+                "(call .cuda()); there is no CPU fallback"
+            )
+        _lib.load()
+        plan: List[_Unit] = [_Unit("stem", self._pack(self.conv1, self.bn1, "conv1"))]
+        plan.append(_Unit("maxpool", kernel=(2, 3, 3), stride=(2, 2, 2)))
+        for lname in ("layer1", "layer2", "layer3", "layer4"):
+            for bi, blk in enumerate(getattr(self, lname)):
+                p = f"{lname}.{bi}"
+                ds = None
+                if blk.downsample is not None:
+                    ds = self._pack(blk.downsample[0], blk.downsample[1], f"{p}.downsample")
+                plan.append(_Unit(
+                    "bottleneck",
+                    self._pack(blk.conv1, blk.bn1, f"{p}.conv1"),
+                    self._pack(blk.conv2, blk.bn2, f"{p}.conv2"),
+                    self._pack(blk.conv3, blk.bn3, f"{p}.conv3"),
+                    ds, name=p,
+                ))
+            if lname == "layer1":
+                plan.append(_Unit("maxpool", kernel=(2, 1, 1), stride=(2, 1, 1)))
+        plan.append(_Unit("avgpool"))
+        self._plan, self._plan_stamp = plan, stamp
+
+    def packed_convs(self) -> List[ops.PackedConv]:
+        self.prepare()
+        out = []
+        for u in self._plan:
+            out.extend(c for c in u.convs if c is not None)
+        return out
+
+    # ------------------------------------------------------------------ forward
+    def forward_single(self, x: torch.Tensor, taps: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+        if self.training:
+            raise _lib.HipExtensionError(
+                "I3Res50 HIP path implements eval-mode BatchNorm (running statistics) only; call .eval() "
+                "as extract_features.load_feature_extraction_model does (extract_features.py:36)"
+            )
+        if x.dim() != 5 or x.shape[1] != 3:
+            raise ValueError(f"expected (B,3,T,H,W), got {tuple(x.shape)}")
+        if x.dtype != torch.float32:
+            raise _lib.HipExtensionError(f"input dtype {x.dtype}: the backbone computes in fp32")
+        if not x.is_cuda:
+            raise _lib.HipExtensionError("input is not on the GPU; there is no CPU fallback")
+        self.prepare()
+        with torch.no_grad():
+            x = x.detach().contiguous()
+            for u in self._plan:
+                x = u.run(x)
+                if taps is not None and u.name:
+                    taps[u.name] = x
+        return x
+
+    def forward(self, batch):
+        return self.forward_single(batch)
+
+
+class _Unit:
+    """One step of the flat execution plan."""
+
+    def __init__(self, kind, *convs, name: str = "", kernel=None, stride=None):
+        self.kind = kind
+        self.convs = convs
+        self.name = name or kind
+        self.kernel, self.stride = kernel, stride
+
+    def run(self, x: torch.Tensor) -> torch.Tensor:
+        if self.kind == "stem":
+            return ops.conv3d_bn_act(x, self.convs[0], relu=True)
+        if self.kind == "maxpool":
+            return ops.maxpool3d(x, self.kernel, self.stride)
+        if self.kind == "avgpool":
+            return ops.global_avgpool(x)
+        c1, c2, c3, ds = self.convs
+        out = ops.conv3d_bn_act(x, c1, relu=True)
+        out = ops.conv3d_bn_act(out, c2, relu=True)
+        res = ops.conv3d_bn_act(x, ds, relu=False) if ds is not None else x
+        return ops.conv3d_bn_act(out, c3, relu=True, residual=res)
+
+
+def print_model_size(model):
+    bits = 0
+    for p in model.parameters():
+        info = torch.finfo(p.dtype) if p.is_floating_point() else torch.iinfo(p.dtype)
+        bits += p.numel() * info.bits
+    print(f"model size: {bits} / bit | {bits / 8e6:.2f} / MB")
+
+
+def build_i3d_feature_extractor(
+    model_name: str = "tushar-n-baseline",
+    check_model_size: bool = True,
+    strict: bool = False,
+    state_dict_path: Optional[str] = None,
+):
+    """Factory with the reference's signature (src/i3d.py:332-364) plus `state_dict_path`.
+
+    Weight source, in order: `state_dict_path`, $ADV_I3D_WEIGHTS, the HF hub file the reference
+    uses (needs network), and -- only when $ADV_I3D_SYNTHETIC=1 -- the deterministic synthetic
+    weights of `weights.synth_i3d_state_dict` (benchmarks / tests; never silently).
+    """
+    if model_name == "tushar-n-baseline":
+        model = I3Res50(use_nl=False)
+    elif model_name == "i3d_8x8_r50":
+        raise NotImplementedError(
+            "i3d_8x8_r50 is pytorchvideo's create_resnet (third-party, not vendored in the reference; "
+            "parity unpinned) -- see DESIGN.md 'next rows'. Use model_name='tushar-n-baseline'."
+        )
+    else:
+        raise AttributeError
+
+    path = state_dict_path or os.environ.get("ADV_I3D_WEIGHTS")
+    if path is None and os.environ.get("ADV_I3D_SYNTHETIC") == "1":
+        from .weights import synth_i3d_state_dict
+
+        sd = synth_i3d_state_dict()
+    else:
+        if path is None:
+            from huggingface_hub import hf_hub_download
+
+            path = hf_hub_download(repo_id=repo_id, filename=model_zoo[model_name])
+        sd = torch.load(path, map_location="cpu")
+    model.load_state_dict(state_dict=sd, strict=strict)
+    if check_model_size:
+        print_model_size(model)
+    return model

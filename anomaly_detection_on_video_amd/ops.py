@@ -1,0 +1,135 @@
+"""Thin Python wrappers over the C ABI (include/advhip.h): shape checks, output allocation
+(torch is used only for device memory and streams) and the launch on torch's current stream.
+
+Every function here REQUIRES CUDA tensors and the built HIP extension; none has a fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check, ptr, require_gpu, stream
+
+
+def _triple(v) -> Tuple[int, int, int]:
+    if isinstance(v, int):
+        return (v, v, v)
+    v = tuple(int(i) for i in v)
+    assert len(v) == 3
+    return v
+
+
+def conv_out_dims(in_thw: Sequence[int], k: Sequence[int], s: Sequence[int], p: Sequence[int]) -> Tuple[int, int, int]:
+    return tuple((n + 2 * pp - kk) // ss + 1 for n, kk, ss, pp in zip(in_thw, k, s, p))  # type: ignore
+
+
+@dataclass
+class PackedConv:
+    """Load-time state of one conv+BN unit: packed weights, folded BN, gather tables per input size."""
+
+    cout: int
+    cin: int
+    kernel: Tuple[int, int, int]
+    stride: Tuple[int, int, int]
+    padding: Tuple[int, int, int]
+    w_packed: torch.Tensor  # [Kpad, Cout]
+    scale: torch.Tensor
+    shift: torch.Tensor
+    ktabs: Dict[Tuple[int, int, int], torch.Tensor] = field(default_factory=dict)
+    algo: int = _lib.ALGO_AUTO
+    name: str = ""
+
+    def desc(self, B: int, T: int, H: int, W: int, relu: bool, algo: Optional[int] = None) -> ConvDesc:
+        kt, kh, kw = self.kernel
+        st, sh, sw = self.stride
+        pt, ph, pw = self.padding
+        return ConvDesc(B, self.cin, T, H, W, self.cout, kt, kh, kw, st, sh, sw, pt, ph, pw, int(relu),
+                        self.algo if algo is None else algo, 0)
+
+
+def bn_fold(gamma, beta, mean, var, eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """eval-mode BatchNorm -> (scale, shift) on device."""
+    require_gpu(gamma, beta, mean, var)
+    lib = _lib.load()
+    c = gamma.numel()
+    scale = torch.empty(c, device=gamma.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    check(lib.advhip_bn_fold_f32(ptr(gamma), ptr(beta), ptr(mean), ptr(var), C.c_float(eps), c, ptr(scale), ptr(shift), stream()), "bn_fold")
+    return scale, shift
+
+
+def _packed_rows(d: ConvDesc) -> int:
+    kpad = _lib.load().advhip_conv3d_packed_rows(C.byref(d))
+    if kpad < 0:
+        check(kpad, "conv3d_packed_rows")
+    return kpad
+
+
+def _build_ktab(pc: PackedConv, thw: Tuple[int, int, int]) -> torch.Tensor:
+    d = pc.desc(1, *thw, relu=False)
+    ktab = torch.empty((_packed_rows(d), 4), device=pc.w_packed.device, dtype=torch.int32)
+    check(_lib.load().advhip_conv3d_build_ktab(C.byref(d), ptr(ktab), stream()), "build_ktab")
+    return ktab
+
+
+def pack_conv(weight: torch.Tensor, gamma, beta, mean, var, eps: float, stride, padding, name: str = "",
+              algo: int = _lib.ALGO_AUTO) -> PackedConv:
+    """Pack one conv (torch layout (Cout,Cin,kt,kh,kw)) + its eval BatchNorm for the HIP kernels."""
+    require_gpu(weight)
+    weight = weight.detach().contiguous()
+    cout, cin, kt, kh, kw = weight.shape
+    scale, shift = bn_fold(gamma.detach(), beta.detach(), mean.detach(), var.detach(), eps)
+    pc = PackedConv(cout, cin, (kt, kh, kw), _triple(stride), _triple(padding), weight, scale, shift, name=name, algo=algo)
+    d = pc.desc(1, kt, kh, kw, relu=False)
+    wp = torch.empty((_packed_rows(d), cout), device=weight.device, dtype=torch.float32)
+    check(_lib.load().advhip_conv3d_pack_weight_f32(C.byref(d), ptr(weight), ptr(wp), stream()), "pack_weight")
+    pc.w_packed = wp
+    return pc
+
+
+def conv3d_bn_act(x: torch.Tensor, pc: PackedConv, relu: bool = True, residual: Optional[torch.Tensor] = None,
+                  algo: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(conv3d(x) * scale + shift (+ residual)) in one fused HIP launch."""
+    require_gpu(x, residual)
+    if x.dim() != 5 or x.shape[1] != pc.cin:
+        raise ValueError(f"{pc.name}: expected (B,{pc.cin},T,H,W), got {tuple(x.shape)}")
+    B, _, T, H, W = x.shape
+    to, ho, wo = conv_out_dims((T, H, W), pc.kernel, pc.stride, pc.padding)
+    if min(to, ho, wo) <= 0:
+        raise ValueError(f"{pc.name}: input {tuple(x.shape)} smaller than the kernel")
+    y = out if out is not None else torch.empty((B, pc.cout, to, ho, wo), device=x.device, dtype=torch.float32)
+    if residual is not None and residual.shape != y.shape:
+        raise ValueError(f"{pc.name}: residual {tuple(residual.shape)} != output {tuple(y.shape)}")
+    key = (T, H, W)
+    ktab = pc.ktabs.get(key)
+    if ktab is None:
+        ktab = pc.ktabs[key] = _build_ktab(pc, key)
+    d = pc.desc(B, T, H, W, relu, algo)
+    lib = _lib.load()
+    check(lib.advhip_conv3d_bn_act_f32(C.byref(d), ptr(x), ptr(pc.w_packed), ptr(ktab), ptr(pc.scale), ptr(pc.shift),
+                                       ptr(residual), ptr(y), stream()), f"conv3d[{pc.name}]")
+    return y
+
+
+def maxpool3d(x: torch.Tensor, kernel, stride) -> torch.Tensor:
+    require_gpu(x)
+    B, Cc, T, H, W = x.shape
+    k, s = _triple(kernel), _triple(stride)
+    to, ho, wo = conv_out_dims((T, H, W), k, s, (0, 0, 0))
+    y = torch.empty((B, Cc, to, ho, wo), device=x.device, dtype=torch.float32)
+    check(_lib.load().advhip_maxpool3d_f32(ptr(x), ptr(y), B, Cc, T, H, W, *k, *s, stream()), "maxpool3d")
+    return y
+
+
+def global_avgpool(x: torch.Tensor) -> torch.Tensor:
+    """(B,C,T,H,W) -> (B,C,1,1,1)"""
+    require_gpu(x)
+    B, Cc = x.shape[:2]
+    n = x[0, 0].numel()
+    y = torch.empty((B, Cc, 1, 1, 1), device=x.device, dtype=torch.float32)
+    check(_lib.load().advhip_global_avgpool_f32(ptr(x), ptr(y), B * Cc, n, stream()), "global_avgpool")
+    return y

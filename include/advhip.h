@@ -1,0 +1,163 @@
+/*
+ * advhip.h -- C ABI of libadvhip.so: hand-written gfx950 (MI355X / CDNA4) HIP kernels for the
+ * I3D-ResNet50 feature-extraction + MGFN MIL-scoring hot path of
+ * jinmang2/anomaly_detection_on_video.
+ *
+ * The reference has no FFI: its hot path calls torch.nn modules.  Each entry point below names
+ * the reference call site(s) it replaces (paths relative to /root/reference).  INTEGRATION.md
+ * shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - all tensors are fp32, contiguous, channels-first (NCDHW / NCT) device pointers owned by
+ *     the caller; nothing is allocated, freed or synchronised inside a call (graph-capturable)
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); launches are asynchronous
+ *   - return value: 0 on success, a negative ADVHIP_E* code otherwise; no exceptions cross the
+ *     ABI; advhip_last_error() returns a thread-local message for the last failure
+ *   - no global mutable state besides that message: thread-compatible, one process per GPU
+ */
+#ifndef ADVHIP_H
+#define ADVHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADVHIP_ABI_VERSION 1
+
+#define ADVHIP_OK 0
+#define ADVHIP_EINVAL (-1)   /* bad shape / null pointer / unsupported configuration */
+#define ADVHIP_ELAUNCH (-2)  /* hipLaunch failed (message has hipGetErrorString) */
+#define ADVHIP_ERANGE (-3)   /* tensor too large for 32-bit element indexing */
+
+/* conv algorithm selector (advhip_conv3d_desc.algo) */
+#define ADVHIP_ALGO_AUTO 0
+#define ADVHIP_ALGO_IGEMM_128x128 1 /* generic implicit GEMM, 128(M) x 128(N) block tile */
+#define ADVHIP_ALGO_IGEMM_128x64 2
+#define ADVHIP_ALGO_IGEMM_64x64 3
+#define ADVHIP_ALGO_IGEMM_64x128 4
+#define ADVHIP_ALGO_STEM 16 /* dedicated Cin=3 k(5,7,7) s2 kernel, LDS halo tile */
+
+typedef struct advhip_conv3d_desc {
+  int32_t B, Cin, T, H, W;    /* input  (B, Cin, T, H, W) */
+  int32_t Cout, kt, kh, kw;   /* weight (Cout, Cin, kt, kh, kw), bias-free */
+  int32_t st, sh, sw;         /* stride */
+  int32_t pt, ph, pw;         /* zero padding */
+  int32_t relu;               /* apply max(0,.) last */
+  int32_t algo;               /* ADVHIP_ALGO_* */
+  int32_t reserved;
+} advhip_conv3d_desc;
+
+/* --- library ------------------------------------------------------------------------------ */
+int advhip_abi_version(void);
+const char* advhip_last_error(void);
+/* "gfx950" -- the only code object in the library */
+const char* advhip_target_arch(void);
+
+/* --- I3D backbone ---------------------------------------------------------------------------
+ * Output extents of a conv / pool (floor mode), the torch formula. */
+int advhip_conv3d_out_dims(const advhip_conv3d_desc* d, int32_t* To, int32_t* Ho, int32_t* Wo);
+
+/* Rows of the packed weight matrix: K = Cin*kt*kh*kw rounded up to a multiple of 16. */
+int advhip_conv3d_packed_rows(const advhip_conv3d_desc* d);
+
+/* Pack torch-layout weights w[Cout][Cin][kt][kh][kw] into the kernels' [Kpad][Cout] layout
+ * (row k = ((ci*kt+dt)*kh+dh)*kw+dw, zero rows above K).  Done once per layer at load time: the
+ * load-time analogue of model.load_state_dict (src/i3d.py:356-359). */
+int advhip_conv3d_pack_weight_f32(const advhip_conv3d_desc* d, const float* w, float* w_packed,
+                                  void* stream);
+
+/* Per-row gather table for one input size (d->T, d->H, d->W):
+ * ktab[k] = {input element offset of tap k relative to the window origin, dt, dh, dw}; rows
+ * above K are marked out-of-range so they contribute exact zeros.  int32[Kpad][4]. */
+int advhip_conv3d_build_ktab(const advhip_conv3d_desc* d, int32_t* ktab, void* stream);
+
+/* Fold eval-mode BatchNorm into per-channel scale/shift:
+ *   scale = gamma / sqrt(var + eps), shift = beta - mean * scale.
+ * Replaces nn.BatchNorm3d in eval mode (src/i3d.py:75,84,88,210,271). */
+int advhip_bn_fold_f32(const float* gamma, const float* beta, const float* mean, const float* var,
+                       float eps, int32_t C, float* scale, float* shift, void* stream);
+
+/* y = act( conv3d(x, w) * scale[c] + shift[c] (+ residual) )  -- one fused launch.
+ * Replaces the nn.Conv3d -> nn.BatchNorm3d -> (+=residual) -> nn.ReLU module sequences of
+ * Bottleneck.forward (src/i3d.py:98-121), the stem (src/i3d.py:303-305) and the downsample
+ * branch (src/i3d.py:262-272).  `residual` may be NULL; otherwise it has y's shape.
+ * fp32 MFMA (v_mfma_f32_16x16x4_f32): exact fp32 products, fp32 accumulation. */
+int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float* x, const float* w_packed,
+                             const int32_t* ktab, const float* scale, const float* shift,
+                             const float* residual, float* y, void* stream);
+
+/* nn.MaxPool3d with zero padding=0, floor mode (src/i3d.py:212-217, 306, 309). */
+int advhip_maxpool3d_f32(const float* x, float* y, int32_t B, int32_t C, int32_t T, int32_t H,
+                         int32_t W, int32_t kt, int32_t kh, int32_t kw, int32_t st, int32_t sh,
+                         int32_t sw, void* stream);
+
+/* nn.AdaptiveAvgPool3d((1,1,1)) (src/i3d.py:244, 314): x (rows, n) -> y (rows), mean over n. */
+int advhip_global_avgpool_f32(const float* x, float* y, int64_t rows, int32_t n, void* stream);
+
+/* --- MIL scorer (MGFN head) -----------------------------------------------------------------
+ * Fused magnitude / score reduction of magnitude_selection_and_score_prediction
+ * (src/models/mgfn/modeling_mgfn.py:314-319): for features (bs*ncrops, T, F) and per-crop scores
+ * (bs*ncrops, T): mag[b,t] = mean_c ||features[b*ncrops+c, t, :]||_2, sc[b,t] = mean_c scores. */
+int advhip_mil_magnitude_f32(const float* features, const float* scores, float* mag, float* sc,
+                             int32_t bs, int32_t ncrops, int32_t T, int32_t F, void* stream);
+
+/* Top-k over T of mag*keep (ties -> lowest index first, as torch.topk on CPU/ROCm for distinct
+ * values; modeling_mgfn.py:345-346), gather of the k selected feature rows for every crop in
+ * crop-major order (modeling_mgfn.py:349-355) and mean of the k selected scores (:359-362).
+ *   mag, keep, sc : (n, T)         features : (n*ncrops, T, F)   [row = video*ncrops + crop]
+ *   idx  : (n, k) int64            sel      : (ncrops*n, k, F)   [row = crop*n + video]
+ *   score: (n)                     keep may be NULL (all ones).   T <= 4096, k <= 16. */
+int advhip_mil_topk_select_f32(const float* mag, const float* keep, const float* sc,
+                               const float* features, int64_t* idx, float* sel, float* score,
+                               int32_t n, int32_t ncrops, int32_t T, int32_t F, int32_t k,
+                               void* stream);
+
+/* Backward of the gather + score mean: scatter-add of d_sel into d_features (must be
+ * zero-initialised by the caller) and of d_score/k into d_sc. */
+int advhip_mil_topk_select_bwd_f32(const int64_t* idx, const float* d_sel, const float* d_score,
+                                   float* d_features, float* d_sc, int32_t n, int32_t ncrops,
+                                   int32_t T, int32_t F, int32_t k, void* stream);
+
+/* Backward of advhip_mil_magnitude_f32 w.r.t. features and scores:
+ *   d_features[r,t,:] += d_mag[b,t]/ncrops * features[r,t,:]/||features[r,t,:]||,
+ *   d_scores[r,t]     += d_sc[b,t]/ncrops                      (r = b*ncrops + c). */
+int advhip_mil_magnitude_bwd_f32(const float* features, const float* d_mag, const float* d_sc,
+                                 float* d_features, float* d_scores, int32_t bs, int32_t ncrops,
+                                 int32_t T, int32_t F, void* stream);
+
+/* Fused loss reductions (src/loss/base.py:7-48, src/loss/mgfn.py:7-47, modeling_mgfn.py:406-418).
+ * Inputs: scores (bs,T) video-level scores; abn/nor_score (n) top-k mean scores (n = bs/2);
+ *         a_feat/n_feat (ncrops*n, k, F) selected features; labels (n) each.
+ * out[0..7] = {total, bce, con, con_a, con_n, smooth, sparse, mgfn}.
+ * `ws` is caller scratch of advhip_mgfn_loss_ws_floats(...) floats (holds the L1 norms). */
+int64_t advhip_mgfn_loss_ws_floats(int32_t n, int32_t ncrops, int32_t k);
+int advhip_mgfn_loss_fwd_f32(const float* scores, const float* abn_score, const float* nor_score,
+                             const float* a_feat, const float* n_feat, const float* abn_labels,
+                             const float* nor_labels, float* ws, float* out, int32_t bs, int32_t T,
+                             int32_t ncrops, int32_t k, int32_t F, void* stream);
+
+/* Gradients of out[0] (times *d_loss) w.r.t. scores, abn/nor_score, a_feat, n_feat. */
+int advhip_mgfn_loss_bwd_f32(const float* d_loss, const float* scores, const float* abn_score,
+                             const float* nor_score, const float* a_feat, const float* n_feat,
+                             const float* abn_labels, const float* nor_labels, const float* ws,
+                             float* d_scores, float* d_abn_score, float* d_nor_score,
+                             float* d_a_feat, float* d_n_feat, int32_t bs, int32_t T,
+                             int32_t ncrops, int32_t k, int32_t F, void* stream);
+
+/* --- feature post-processing (on-device analogues of host numpy code) -------------------------
+ * segment(): (n_clips, ncrops, C) -> (ncrops, seg, C) linspace-bucket means
+ * (extract_features.py:171-183). */
+int advhip_segment_features_f32(const float* feats, float* out, int32_t n_clips, int32_t ncrops,
+                                int32_t C, int32_t seg, void* stream);
+
+/* FeatureDataset.add_magnitude (src/dataset.py:121-124): (rows, C) -> (rows, C+1), last column
+ * = L2 norm of the row. */
+int advhip_add_magnitude_f32(const float* feats, float* out, int64_t rows, int32_t C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADVHIP_H */

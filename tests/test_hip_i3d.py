@@ -1,0 +1,215 @@
+"""GPU parity tests for the I3D backbone kernels (run with -m gpu on an MI355X).
+
+Every comparison is HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs, or
+vs the golden vectors made by the reference's own code.  Tolerance: north_star's 1e-3 relative
+(norm-wise, max|a-b|/max|b|); the fp32-MFMA path is expected to land around 1e-6.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_err
+from anomaly_detection_on_video_amd.weights import synth_i3d_state_dict, synth_input, synth_tensor
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3        # the contract
+TIGHT = 2e-5      # what exact-fp32 MFMA should actually achieve per conv
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+# (name, Cin, Cout, kernel, stride, padding, (B,T,H,W))  -- every distinct conv config of I3Res50
+#  on reduced batch / spatial extents, plus edge cases
+CONV_CASES = [
+    ("stem", 3, 64, (5, 7, 7), (2, 2, 2), (2, 3, 3), (2, 8, 36, 28)),
+    ("l1.conv1.t3", 64, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 4, 13, 11)),
+    ("l1.conv2", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 4, 13, 11)),
+    ("l1.conv3", 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 13, 11)),
+    ("l1.conv1b", 256, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 4, 9, 7)),
+    ("l2.conv1", 256, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 2, 11, 11)),
+    ("l2.conv2.s2", 128, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 2, 11, 11)),
+    ("l2.conv3", 128, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 2, 6, 6)),
+    ("l2.ds.s2", 256, 512, (1, 1, 1), (1, 2, 2), (0, 0, 0), (2, 2, 11, 11)),
+    ("l2.conv1.k1", 512, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 6, 6)),
+    ("l2.conv2", 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 2, 6, 6)),
+    ("l2.conv1.t3", 512, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 2, 6, 6)),
+    ("l3.conv1", 512, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 2, 6, 6)),
+    ("l3.conv2.s2", 256, 256, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 2, 6, 6)),
+    ("l3.conv3", 256, 1024, (1, 1, 1), (1, 1, 1), (0, 0, 0), (3, 2, 3, 3)),
+    ("l3.ds.s2", 512, 1024, (1, 1, 1), (1, 2, 2), (0, 0, 0), (1, 2, 6, 6)),
+    ("l3.conv1.k1", 1024, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 2, 3, 3)),
+    ("l3.conv2", 256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 2, 3, 3)),
+    ("l3.conv1.t3", 1024, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 2, 3, 3)),
+    ("l4.conv1", 1024, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 2, 3, 3)),
+    ("l4.conv2.s2", 512, 512, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 2, 3, 3)),
+    ("l4.conv3", 512, 2048, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 2, 2, 2)),
+    ("l4.ds.s2", 1024, 2048, (1, 1, 1), (1, 2, 2), (0, 0, 0), (2, 2, 3, 3)),
+    ("l4.conv1.t3", 2048, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 2, 2, 2)),
+    ("l4.conv2", 512, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 2, 2, 2)),
+    ("l4.conv1.k1", 2048, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 2, 2, 2)),
+    # edge cases: full-size 7x7 frames (THW = 98, not a multiple of 4), single output position,
+    # odd extents everywhere, output smaller than one tile
+    ("edge.7x7", 512, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1), (3, 2, 7, 7)),
+    ("edge.1pos", 64, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1, 1)),
+    ("edge.odd", 64, 128, (3, 3, 3), (1, 2, 1), (1, 0, 2), (1, 3, 5, 7)),
+    ("edge.55", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 55, 55)),
+]
+
+
+def _conv_case(name, cin, cout, k, s, p, bthw):
+    from oracle import i3d_oracle
+
+    b, t, h, w = bthw
+    fan = cin * k[0] * k[1] * k[2]
+    x = synth_tensor(f"conv.{name}.x", (b, cin, t, h, w), scale=2.0)
+    wt = synth_tensor(f"conv.{name}.w", (cout, cin) + tuple(k), scale=float(np.sqrt(6.0 / fan)))
+    g = synth_tensor(f"conv.{name}.g", (cout,), scale=0.5, offset=1.0)
+    be = synth_tensor(f"conv.{name}.b", (cout,), scale=0.25)
+    mu = synth_tensor(f"conv.{name}.m", (cout,), scale=0.25)
+    var = synth_tensor(f"conv.{name}.v", (cout,), scale=0.5, offset=1.0)
+    y0 = i3d_oracle.conv_bn_act(x, wt, g, be, mu, var, s, p, None, relu=False)
+    res = synth_tensor(f"conv.{name}.r", tuple(y0.shape), scale=1.0)
+    return x, wt, g, be, mu, var, res
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4], ids=["auto", "128x128", "128x64", "64x64", "64x128"])
+def test_conv_bn_act_vs_oracle(case, algo):
+    from anomaly_detection_on_video_amd import ops
+    from oracle import i3d_oracle
+
+    name, cin, cout, k, s, p, bthw = case
+    if algo in (1, 4) and cout % 128:
+        pytest.skip("Cout not a multiple of the 128-wide N tile")
+    x, wt, g, be, mu, var, res = _conv_case(*case)
+    dev = _dev()
+    pc = ops.pack_conv(wt.to(dev), g.to(dev), be.to(dev), mu.to(dev), var.to(dev), 1e-5, s, p, name=name)
+    for use_res, relu in ((False, True), (True, True), (True, False)):
+        ref = i3d_oracle.conv_bn_act(x, wt, g, be, mu, var, s, p, res if use_res else None, relu)
+        out = ops.conv3d_bn_act(x.to(dev), pc, relu=relu, residual=res.to(dev) if use_res else None, algo=algo)
+        torch.cuda.synchronize()
+        assert out.shape == ref.shape
+        e = rel_err(out.cpu(), ref)
+        assert e < TIGHT, f"{name} algo={algo} res={use_res} relu={relu}: rel err {e:.3e}"
+        assert e < TOL
+
+
+@pytest.mark.parametrize("shape,k,s", [
+    ((2, 64, 8, 28, 30), (2, 3, 3), (2, 2, 2)),   # maxpool1 (odd output extents)
+    ((2, 256, 4, 11, 13), (2, 1, 1), (2, 1, 1)),  # maxpool2
+    ((1, 3, 5, 7, 9), (1, 2, 3), (1, 1, 2)),
+])
+def test_maxpool3d_bit_exact(shape, k, s):
+    from anomaly_detection_on_video_amd import ops
+
+    x = synth_tensor(f"pool.{shape}", shape, scale=3.0)
+    ref = torch.nn.functional.max_pool3d(x, k, s)
+    out = ops.maxpool3d(x.to(_dev()), k, s).cpu()
+    assert torch.equal(out, ref)  # pure selection: bit exact
+
+
+def test_global_avgpool():
+    from anomaly_detection_on_video_amd import ops
+
+    x = synth_tensor("avgpool", (3, 2048, 2, 7, 7), scale=20.0).abs()
+    ref = torch.nn.functional.adaptive_avg_pool3d(x, 1)
+    out = ops.global_avgpool(x.to(_dev())).cpu()
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < 1e-6
+
+
+@pytest.fixture(scope="module")
+def model():
+    from anomaly_detection_on_video_amd.i3d import I3Res50
+
+    m = I3Res50(use_nl=False)
+    m.load_state_dict(synth_i3d_state_dict(), strict=True)
+    return m.eval().to(_dev())
+
+
+def test_fullnet_vs_reference_golden(model):
+    g = np.load(os.path.join(GOLDEN, "i3d_fullnet.npz"))
+    for seed in (0, 1):
+        x = synth_input((2, 3, 16, 224, 224), seed).to(_dev())
+        y = model(x)
+        assert y.shape == (2, 2048, 1, 1, 1)
+        e = rel_err(y.reshape(2, 2048).cpu(), g[f"feat_seed{seed}"])
+        assert e < TOL, f"seed {seed}: rel err {e:.3e}"
+        assert e < 1e-4, f"fp32-exact path drifted: {e:.3e}"
+    x = synth_input((1, 3, 8, 112, 96), 7).to(_dev())
+    e = rel_err(model(x).reshape(1, 2048).cpu(), g["feat_small"])
+    assert e < TOL and e < 1e-4
+
+
+def test_fullnet_stage_taps_vs_reference_golden(model):
+    g = np.load(os.path.join(GOLDEN, "i3d_fullnet.npz"))
+    x = synth_input((2, 3, 16, 224, 224), 0).to(_dev())
+    taps = {}
+    model.forward_single(x, taps)
+    seen = 0
+    for name, v in taps.items():
+        key = f"stat_{name}"
+        if key not in g.files:
+            continue
+        ref = g[key]
+        v = v.cpu()
+        flat = v.reshape(-1)
+        idx = torch.linspace(0, flat.numel() - 1, 64).long()
+        assert rel_err(flat[idx], ref[3:]) < TOL, name
+        assert abs(v.mean().item() - ref[0]) <= 1e-3 * max(1.0, abs(ref[0])), name
+        seen += 1
+    assert seen >= 16
+
+
+def test_bottleneck_blocks_vs_reference_golden():
+    """The HIP conv chain for one Bottleneck vs the reference's own Bottleneck outputs."""
+    from test_oracle_golden import BLOCK_CASES, micro_block_case
+    from anomaly_detection_on_video_amd import ops
+
+    dev = _dev()
+    for name in BLOCK_CASES:
+        c = micro_block_case(name)
+        sd, s, tc = c["sd"], c["stride"], c["tc"]
+
+        def pk(conv, bn, stride, pad):
+            return ops.pack_conv(sd[f"{conv}.weight"].to(dev), sd[f"{bn}.weight"].to(dev), sd[f"{bn}.bias"].to(dev),
+                                 sd[f"{bn}.running_mean"].to(dev), sd[f"{bn}.running_var"].to(dev), 1e-5, stride, pad)
+
+        x = c["x"].to(dev)
+        o = ops.conv3d_bn_act(x, pk("conv1", "bn1", (1, 1, 1), (tc, 0, 0)), relu=True)
+        o = ops.conv3d_bn_act(o, pk("conv2", "bn2", (1, s, s), (0, 1, 1)), relu=True)
+        r = ops.conv3d_bn_act(x, pk("downsample.0", "downsample.1", (1, s, s), (0, 0, 0)), relu=False) if c["has_ds"] else x
+        o = ops.conv3d_bn_act(o, pk("conv3", "bn3", (1, 1, 1), (0, 0, 0)), relu=True, residual=r)
+        e = rel_err(o.cpu(), c["y"])
+        assert e < TOL and e < 1e-4, f"{name}: {e:.3e}"
+
+
+def test_fullnet_batch_independence_and_determinism(model):
+    """Size-independent properties at the benchmark's full shape: a clip's feature does not depend on
+    what else is in the batch (bit-exact: same kernels, same per-clip arithmetic order), and the
+    forward is deterministic."""
+    x = synth_input((5, 3, 16, 224, 224), 3).to(_dev())
+    y_all = model(x).reshape(5, 2048)
+    y_again = model(x).reshape(5, 2048)
+    assert torch.equal(y_all, y_again)
+    y_one = model(x[3:4].contiguous()).reshape(1, 2048)
+    assert torch.equal(y_all[3:4], y_one)
+    assert torch.isfinite(y_all).all()
+
+
+def test_product_path_refuses_cpu_and_train_mode():
+    from anomaly_detection_on_video_amd import _lib
+    from anomaly_detection_on_video_amd.i3d import I3Res50
+
+    m = I3Res50().eval()
+    with pytest.raises(_lib.HipExtensionError):
+        m(torch.zeros(1, 3, 16, 32, 32))  # CPU tensors: no fallback
+    m = m.to(_dev())
+    m.train()
+    with pytest.raises(_lib.HipExtensionError):
+        m(torch.zeros(1, 3, 16, 32, 32, device=_dev()))
