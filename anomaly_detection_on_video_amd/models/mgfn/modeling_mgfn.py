@@ -1,0 +1,295 @@
+"""MGFN multiple-instance-learning scorer: PyTorch-ROCm body, HIP head and losses.
+
+Drop-in for `/root/reference/src/models/mgfn/modeling_mgfn.py`: same class names, constructor
+(`MGFNForVideoAnomalyDetection(config)`), `forward(video, abnormal_labels, normal_labels)`,
+output dataclass fields, `force_split` property and state-dict keys (145 entries).
+
+What runs where
+  * backbone (amplifier, Glance/Focus blocks: Conv1d / attention / GELU; needs autograd): stock
+    PyTorch-ROCm ops -- plumbing, as SURVEY.md K7/K8 allows;
+  * the MIL head `magnitude_selection_and_score_prediction` (modeling_mgfn.py:302-374) and the
+    four loss terms (loss/base.py, loss/mgfn.py): hand-written wavefront-shuffle HIP kernels with
+    custom backward (`mil_ops.py`; csrc/mil.hip, csrc/loss.hip).
+CUDA tensors only for the head/loss: there is no CPU fallback (calls raise on CPU tensors).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ... import mil_ops
+from .configuration_mgfn import MGFNConfig
+
+try:
+    from transformers import PreTrainedModel as _PreTrainedModel
+    from transformers.utils import ModelOutput as _ModelOutput
+except Exception:  # pragma: no cover - transformers absent: minimal stand-ins
+    _PreTrainedModel = None
+    _ModelOutput = None
+
+
+if _ModelOutput is not None:
+    @dataclass
+    class MGFNModelOutput(_ModelOutput):
+        outputs: torch.FloatTensor = None
+
+    @dataclass
+    class MGFNVideoAnomalyDetectionOutput(_ModelOutput):
+        loss: torch.FloatTensor = None
+        abnormal_scores: torch.FloatTensor = None
+        normal_scores: torch.FloatTensor = None
+        a_feat_magnitude: torch.FloatTensor = None
+        n_feat_magnitude: torch.FloatTensor = None
+        scores: torch.FloatTensor = None
+else:  # pragma: no cover
+    @dataclass
+    class MGFNModelOutput:
+        outputs: torch.Tensor = None
+
+    @dataclass
+    class MGFNVideoAnomalyDetectionOutput:
+        loss: torch.Tensor = None
+        abnormal_scores: torch.Tensor = None
+        normal_scores: torch.Tensor = None
+        a_feat_magnitude: torch.Tensor = None
+        n_feat_magnitude: torch.Tensor = None
+        scores: torch.Tensor = None
+
+
+class MGFNLayerNorm(nn.Module):
+    """Channel-dim norm dividing by (std + eps) -- not sqrt(var + eps) (modeling_mgfn.py:43-46)."""
+
+    def __init__(self, dim: int, eps: float = 1e-5):
+        super().__init__()
+        self.eps = eps
+        self.g = nn.Parameter(torch.ones(1, dim, 1))
+        self.b = nn.Parameter(torch.zeros(1, dim, 1))
+
+    def forward(self, x):
+        var, mean = torch.var_mean(x, dim=1, unbiased=False, keepdim=True)
+        return (x - mean) / (var.sqrt() + self.eps) * self.g + self.b
+
+
+class MGFNFeedForward(nn.Module):
+    def __init__(self, dim: int, repe: int = 4, dropout: float = 0.0):
+        super().__init__()
+        self.layer_norm = MGFNLayerNorm(dim)
+        self.in_conv = nn.Conv1d(dim, dim * repe, 1)
+        self.gelu = nn.GELU()
+        self.dropout = nn.Dropout(dropout)
+        self.out_conv = nn.Conv1d(dim * repe, dim, 1)
+
+    def forward(self, x):
+        return self.out_conv(self.dropout(self.gelu(self.in_conv(self.layer_norm(x)))))
+
+
+class MGFNFeatureAmplifier(nn.Module):
+    """tokens = Conv1d_k3(features) + mag_ratio * Conv1d_k3(magnitude) (modeling_mgfn.py:81-93)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.channels = config.channels
+        self.mag_ratio = config.mag_ratio
+        self.to_tokens = nn.Conv1d(config.channels, config.dims[0], kernel_size=3, stride=1, padding=1)
+        self.to_mag = nn.Conv1d(1, config.dims[0], kernel_size=3, stride=1, padding=1)
+
+    def forward(self, x):
+        bs, ncrops, t, c = x.shape
+        x = x.reshape(bs * ncrops, t, c).transpose(1, 2)
+        return self.to_tokens(x[:, : self.channels]) + self.mag_ratio * self.to_mag(x[:, self.channels :])
+
+
+class GlanceAttention(nn.Module):
+    """Multi-head self-attention over the T clips (modeling_mgfn.py:107-123)."""
+
+    def __init__(self, dim: int, heads: int, dim_head: int):
+        super().__init__()
+        self.heads, self.dim_head = heads, dim_head
+        self.scale = dim_head ** -0.5
+        self.norm = MGFNLayerNorm(dim)
+        self.to_qkv = nn.Conv1d(dim, dim_head * heads * 3, 1, bias=False)
+        self.to_out = nn.Conv1d(dim_head * heads, dim, 1)
+
+    def forward(self, x):
+        b, _, n = x.shape
+        q, k, v = self.to_qkv(self.norm(x)).view(b, 3, self.heads, self.dim_head, n).unbind(1)
+        sim = torch.matmul((q * self.scale).transpose(-1, -2), k)  # (b, h, i, j)
+        out = torch.matmul(v, sim.softmax(dim=-1).transpose(-1, -2))  # (b, h, d, i)
+        return self.to_out(out.reshape(b, self.heads * self.dim_head, n))
+
+
+class FocusAttention(nn.Module):
+    """BN1d -> 1x1 conv -> per-head depth-wise k=5 temporal conv -> 1x1 conv (modeling_mgfn.py:173-180)."""
+
+    def __init__(self, dim: int, heads: int, dim_head: int, local_aggr_kernel: int):
+        super().__init__()
+        self.heads = heads
+        inner = dim_head * heads
+        self.norm = nn.BatchNorm1d(dim)
+        self.to_v = nn.Conv1d(dim, inner, 1, bias=False)
+        self.rel_pos = nn.Conv1d(heads, heads, local_aggr_kernel, padding=local_aggr_kernel // 2, groups=heads)
+        self.to_out = nn.Conv1d(inner, dim, 1)
+
+    def forward(self, x):
+        b, _, n = x.shape
+        v = self.to_v(self.norm(x))
+        inner = v.shape[1]
+        # channel = c_idx*heads + h_idx  ("b (c h) n -> (b c) h n")
+        out = self.rel_pos(v.reshape(b * (inner // self.heads), self.heads, n))
+        return self.to_out(out.reshape(b, inner, n))
+
+
+class _Block(nn.Module):
+    def forward(self, x):
+        x = self.scc(x) + x
+        x = self.attention(x) + x
+        return self.ffn(x) + x
+
+
+class GlanceBlock(_Block):
+    def __init__(self, config, dim: int, heads: int):
+        super().__init__()
+        self.scc = nn.Conv1d(dim, dim, 3, padding=1)
+        self.attention = GlanceAttention(dim=dim, heads=heads, dim_head=config.dim_head)
+        self.ffn = MGFNFeedForward(dim, repe=config.ff_repe, dropout=config.dropout)
+
+
+class FocusBlock(_Block):
+    def __init__(self, config, dim, heads):
+        super().__init__()
+        self.scc = nn.Conv1d(dim, dim, 3, padding=1)
+        self.attention = FocusAttention(dim=dim, heads=heads, dim_head=config.dim_head, local_aggr_kernel=config.local_aggr_kernel)
+        self.ffn = MGFNFeedForward(dim, repe=config.ff_repe, dropout=config.dropout)
+
+
+class MGFNIntermediate(nn.Module):
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.layer_norm = MGFNLayerNorm(in_dim)
+        self.conv = nn.Conv1d(in_dim, out_dim, 1, stride=1)
+
+    def forward(self, x):
+        return self.conv(self.layer_norm(x))
+
+
+if _PreTrainedModel is not None:
+    class MGFNPreTrainedModel(_PreTrainedModel):
+        config_class = MGFNConfig
+        base_model_prefix = "backbone"
+
+        def _init_weights(self, module):  # the reference leaves torch's default init untouched
+            return None
+
+        @property
+        def dummy_inputs(self):
+            return torch.randn(32, 10, 32, 2049)
+else:  # pragma: no cover
+    class MGFNPreTrainedModel(nn.Module):
+        config_class = MGFNConfig
+
+        def __init__(self, config):
+            super().__init__()
+            self.config = config
+
+
+class MGFNModel(MGFNPreTrainedModel):
+    def __init__(self, config):
+        super().__init__(config)
+        self.amplifier = MGFNFeatureAmplifier(config)
+        stages = []
+        n_stages = len(config.depths)
+        for ind, (depth, kind) in enumerate(zip(config.depths, config.mgfn_types)):
+            dim = config.dims[ind]
+            heads = dim // config.dim_head
+            if kind == "gb":
+                cls = GlanceBlock
+            elif kind == "fb":
+                cls = FocusBlock
+            else:
+                raise AttributeError("The type of mgfn block must be either `gb` or `fb`.")
+            blocks = [cls(config, dim=dim, heads=heads) for _ in range(depth)]
+            if ind != n_stages - 1:
+                blocks.append(MGFNIntermediate(dim, config.dims[ind + 1]))
+            stages.append(nn.Sequential(*blocks))
+        self.layers = nn.Sequential(*stages)
+
+    def forward(self, x: torch.Tensor) -> MGFNModelOutput:
+        return MGFNModelOutput(outputs=self.layers(self.amplifier(x)))
+
+
+class MGFNForVideoAnomalyDetection(MGFNPreTrainedModel):
+    def __init__(self, config):
+        super().__init__(config)
+        self.k = config.k
+        last_dim = config.dims[-1]
+        self.backbone = MGFNModel(config)
+        self.layer_norm = nn.LayerNorm(last_dim)
+        self.fc = nn.Linear(last_dim, 1)
+        self.sigmoid = nn.Sigmoid()
+        self._force_split = False
+        self.dropout = nn.Dropout(config.dropout_rate)
+        # test hook: (keep_abnormal, keep_normal) multipliers used instead of drawing dropout masks
+        self.injected_keep: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+        self.last_loss_terms: Optional[torch.Tensor] = None
+        self.last_indices: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+
+    @property
+    def force_split(self) -> bool:
+        """Split the batch into normal/abnormal halves in eval mode too (modeling_mgfn.py:290-300)."""
+        return self._force_split
+
+    @force_split.setter
+    def force_split(self, val: bool):
+        self._force_split = val
+
+    def magnitude_selection_and_score_prediction(self, features, scores, batch_size, ncrops):
+        """HIP restatement of modeling_mgfn.py:302-374; features (bs*ncrops,T,F), scores (bs*ncrops,T,1)."""
+        mag, sc = mil_ops.mil_magnitude(features, scores.squeeze(-1), batch_size, ncrops)
+        if self.force_split or self.training:
+            h = batch_size // 2
+            nf, af = features[: h * ncrops], features[h * ncrops :]
+            nm, am = mag[:h], mag[h:]
+            ns, as_ = sc[:h], sc[h:]
+        else:
+            nf = af = features
+            nm = am = mag
+            ns = as_ = sc
+        if self.injected_keep is not None:
+            keep_a, keep_n = self.injected_keep
+        elif self.training:
+            # same call order as the reference: abnormal first, then normal (modeling_mgfn.py:364-372)
+            keep_a = self.dropout(torch.ones_like(am))
+            keep_n = self.dropout(torch.ones_like(nm))
+        else:
+            keep_a = keep_n = None
+        idx_a, feat_a, score_a = mil_ops.mil_topk_select(am, keep_a, as_, af, ncrops, self.k)
+        idx_n, feat_n, score_n = mil_ops.mil_topk_select(nm, keep_n, ns, nf, ncrops, self.k)
+        self.last_indices = (idx_a, idx_n)
+        return score_a, score_n, feat_a, feat_n, sc.unsqueeze(2)
+
+    def forward(self, video: torch.Tensor, abnormal_labels: Optional[torch.Tensor] = None,
+                normal_labels: Optional[torch.Tensor] = None) -> MGFNVideoAnomalyDetectionOutput:
+        bs, ncrops = video.shape[:2]
+        x = self.backbone(video).outputs.permute(0, 2, 1)  # (bs*ncrops, T, last_dim)
+        x = self.layer_norm(x)
+        scores = self.sigmoid(self.fc(x))
+        abn_s, nor_s, a_feat, n_feat, sc = self.magnitude_selection_and_score_prediction(x, scores, bs, ncrops)
+        loss = None
+        if abnormal_labels is not None and normal_labels is not None:
+            loss, terms = mil_ops.mgfn_loss(sc, abn_s, nor_s, a_feat, n_feat, abnormal_labels, normal_labels, ncrops)
+            self.last_loss_terms = terms
+        return MGFNVideoAnomalyDetectionOutput(
+            loss=loss, abnormal_scores=abn_s, normal_scores=nor_s,
+            a_feat_magnitude=a_feat, n_feat_magnitude=n_feat, scores=sc,
+        )
+
+
+def mgfn_param_shapes(config: Optional[MGFNConfig] = None) -> "OrderedDict[str, Tuple[int, ...]]":
+    """state-dict key -> shape (lets tests build deterministic weights without a reference model)."""
+    m = MGFNForVideoAnomalyDetection(config or MGFNConfig())
+    return OrderedDict((k, tuple(v.shape)) for k, v in m.state_dict().items())

@@ -77,7 +77,7 @@ def glance_attention(x, sd, p, heads, dim_head):
 def focus_attention(x, sd, p, heads, training, kernel):
     # modeling_mgfn.py:173-180
     h = F.batch_norm(
-        x, sd[f"{p}.norm.running_mean"].clone(), sd[f"{p}.norm.running_var"].clone(),
+        x, sd[f"{p}.norm.running_mean"].detach().clone(), sd[f"{p}.norm.running_var"].detach().clone(),
         sd[f"{p}.norm.weight"], sd[f"{p}.norm.bias"], training=training, momentum=0.1, eps=1e-5,
     )
     b, _, n = h.shape

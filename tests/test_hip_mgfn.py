@@ -1,0 +1,227 @@
+"""GPU parity tests for the MIL scorer: HIP head/loss kernels (through the C ABI) + PyTorch-ROCm
+body vs the CPU oracle and the reference-generated goldens.  Tolerance 1e-3 relative (contract);
+the HIP reductions themselves are checked at 1e-5."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_err
+from anomaly_detection_on_video_amd.weights import synth_module_state_dict, synth_tensor
+from test_oracle_golden import mgfn_inputs
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def model_and_sd():
+    from anomaly_detection_on_video_amd.models.mgfn import MGFNConfig, MGFNForVideoAnomalyDetection
+
+    m = MGFNForVideoAnomalyDetection(MGFNConfig())
+    sd = synth_module_state_dict(m, gain=1.0)
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV), sd
+
+
+def _reset(model, sd):
+    model.load_state_dict(sd, strict=True)
+    model.injected_keep = None
+    model.force_split = False
+    for p in model.parameters():
+        p.grad = None
+
+
+def test_state_dict_keys_match_reference(model_and_sd):
+    g = np.load(os.path.join(GOLDEN, "mgfn.npz"))
+    model, _ = model_and_sd
+    assert list(model.state_dict().keys()) == list(g["state_keys"])
+    assert len(model.state_dict()) == 145
+
+
+def test_eval_force_split_scores_losses_grads_vs_reference_golden(model_and_sd):
+    g = np.load(os.path.join(GOLDEN, "mgfn.npz"))
+    model, sd = model_and_sd
+    _reset(model, sd)
+    model.eval()
+    model.force_split = True
+    video = mgfn_inputs(4, 32, 0).to(DEV)
+    nl, al = torch.zeros(2, device=DEV), torch.ones(2, device=DEV)
+    o = model(video=video, abnormal_labels=al, normal_labels=nl)
+    assert o.scores.shape == (4, 32, 1) and o.abnormal_scores.shape == (2, 1)
+    assert o.a_feat_magnitude.shape == (20, 3, 1024)
+    assert rel_err(o.scores.detach().cpu(), g["evalsplit_scores"]) < TOL
+    assert rel_err(o.abnormal_scores.detach().cpu(), g["evalsplit_abn_scores"]) < TOL
+    assert rel_err(o.normal_scores.detach().cpu(), g["evalsplit_nor_scores"]) < TOL
+    assert rel_err(o.a_feat_magnitude.detach().norm(p=1, dim=2).cpu(), g["evalsplit_a_feat_l1"]) < TOL
+    assert rel_err(o.n_feat_magnitude.detach()[..., :32].cpu(), g["evalsplit_n_feat_head"]) < TOL
+    assert rel_err(o.loss.detach().cpu(), g["evalsplit_loss"]) < TOL
+    t = model.last_loss_terms.cpu()
+    assert rel_err(t[5], g["evalsplit_loss_smooth"]) < TOL
+    assert rel_err(t[6], g["evalsplit_loss_sparse"]) < TOL
+    assert rel_err(t[7], g["evalsplit_loss_mgfn"]) < TOL
+    o.loss.backward()
+    assert rel_err(model.fc.weight.grad.cpu(), g["evalsplit_grad_fc_w"]) < TOL
+    gt = model.backbone.amplifier.to_tokens.weight.grad.cpu()
+    assert rel_err(gt.norm(), g["evalsplit_grad_to_tokens_w_norm"]) < TOL
+    flat = gt.reshape(-1)
+    idx = torch.linspace(0, flat.numel() - 1, 64).long()
+    assert rel_err(flat[idx], g["evalsplit_grad_to_tokens_w_sample"]) < TOL
+
+
+def test_training_branch_with_injected_mask_vs_reference_golden(model_and_sd):
+    g = np.load(os.path.join(GOLDEN, "mgfn.npz"))
+    model, sd = model_and_sd
+    _reset(model, sd)
+    model.train()
+    model.injected_keep = (torch.from_numpy(g["train_keep_abn"]).to(DEV), torch.from_numpy(g["train_keep_nor"]).to(DEV))
+    video = mgfn_inputs(4, 32, 0).to(DEV)
+    nl, al = torch.zeros(2, device=DEV), torch.ones(2, device=DEV)
+    o = model(video=video, abnormal_labels=al, normal_labels=nl)
+    assert rel_err(o.scores.detach().cpu(), g["train_scores"]) < TOL
+    assert rel_err(o.abnormal_scores.detach().cpu(), g["train_abn_scores"]) < TOL
+    assert rel_err(o.a_feat_magnitude.detach().norm(p=1, dim=2).cpu(), g["train_a_feat_l1"]) < TOL
+    assert rel_err(o.loss.detach().cpu(), g["train_loss"]) < TOL
+    o.loss.backward()
+    assert rel_err(model.fc.weight.grad.cpu(), g["train_grad_fc_w"]) < TOL
+    _reset(model, sd)
+
+
+def test_eval_no_split_odd_T_vs_reference_golden(model_and_sd):
+    g = np.load(os.path.join(GOLDEN, "mgfn.npz"))
+    model, sd = model_and_sd
+    _reset(model, sd)
+    model.eval()
+    with torch.no_grad():
+        o = model(video=mgfn_inputs(1, 57, 3).to(DEV))
+    assert o.loss is None
+    assert rel_err(o.scores.cpu(), g["eval57_scores"]) < TOL
+    assert rel_err(o.abnormal_scores.cpu(), g["eval57_abn_scores"]) < TOL
+    assert torch.equal(o.abnormal_scores, o.normal_scores)
+
+
+def test_training_mode_draws_dropout_masks(model_and_sd):
+    model, sd = model_and_sd
+    _reset(model, sd)
+    model.train()
+    video = mgfn_inputs(4, 32, 0).to(DEV)
+    o = model(video=video, abnormal_labels=torch.ones(2, device=DEV), normal_labels=torch.zeros(2, device=DEV))
+    assert torch.isfinite(o.loss)
+    o.loss.backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    _reset(model, sd)
+
+
+# ------------------------------------------------------------------ kernel-level (K9 / K10)
+@pytest.mark.parametrize("bs,ncrops,T,F,k,use_keep", [
+    (4, 10, 32, 1024, 3, True), (2, 10, 57, 1024, 3, False), (6, 3, 200, 96, 5, True), (2, 1, 3, 7, 3, False),
+])
+def test_mil_magnitude_and_topk_select_fwd_bwd(bs, ncrops, T, F, k, use_keep):
+    from anomaly_detection_on_video_amd import mil_ops
+    from oracle import mgfn_oracle
+
+    feats = synth_tensor(f"k9.f.{bs}.{T}", (bs * ncrops, T, F), scale=1.0)
+    scores = synth_tensor(f"k9.s.{bs}.{T}", (bs * ncrops, T, 1), scale=0.5, offset=0.5)
+    n = bs // 2
+    keep_a = keep_n = None
+    if use_keep:
+        kk = (synth_tensor(f"k9.keep.{bs}.{T}", (2, n, T), scale=0.5, offset=0.5) < 0.4).float() / 0.3
+        keep_a, keep_n = kk[0], kk[1]
+    # oracle (CPU autograd)
+    fc = feats.clone().requires_grad_(True)
+    sc_ = scores.clone().requires_grad_(True)
+    sa, sn, fa, fn, sc, ia, in_ = mgfn_oracle.mil_select(fc, sc_, bs, ncrops, k, True, keep_a, keep_n)
+    wa = synth_tensor("k9.wa", tuple(fa.shape), scale=1.0)
+    wn = synth_tensor("k9.wn", tuple(fn.shape), scale=1.0)
+    wsc = synth_tensor("k9.wsc", tuple(sc.shape), scale=1.0)
+    obj = (fa * wa).sum() + (fn * wn).sum() * 0.5 + sa.sum() * 3 + sn.sum() * 2 + (sc * wsc).sum()
+    obj.backward()
+    # HIP
+    fg = feats.to(DEV).requires_grad_(True)
+    sg = scores.to(DEV).requires_grad_(True)
+    mag, scv = mil_ops.mil_magnitude(fg, sg.squeeze(-1), bs, ncrops)
+    ref_mag = torch.norm(feats, p=2, dim=2).view(bs, ncrops, -1).mean(1)
+    assert rel_err(mag.detach().cpu(), ref_mag) < 1e-5
+    assert rel_err(scv.detach().cpu(), sc.detach().squeeze(-1)) < 1e-5
+    h = n * ncrops
+    ka = None if keep_a is None else keep_a.to(DEV)
+    kn = None if keep_n is None else keep_n.to(DEV)
+    idx_a, sel_a, s_a = mil_ops.mil_topk_select(mag[n:], ka, scv[n:], fg[h:], ncrops, k)
+    idx_n, sel_n, s_n = mil_ops.mil_topk_select(mag[:n], kn, scv[:n], fg[:h], ncrops, k)
+    assert torch.equal(idx_a.cpu(), ia) and torch.equal(idx_n.cpu(), in_)
+    assert torch.equal(sel_a.detach().cpu(), fa.detach()) and torch.equal(sel_n.detach().cpu(), fn.detach())  # pure gather: bit exact
+    assert rel_err(s_a.detach().cpu(), sa.detach()) < 1e-5 and rel_err(s_n.detach().cpu(), sn.detach()) < 1e-5
+    obj2 = (sel_a * wa.to(DEV)).sum() + (sel_n * wn.to(DEV)).sum() * 0.5 + s_a.sum() * 3 + s_n.sum() * 2 + (scv.unsqueeze(2) * wsc.to(DEV)).sum()
+    obj2.backward()
+    assert rel_err(fg.grad.cpu(), fc.grad) < 1e-5
+    assert rel_err(sg.grad.cpu(), sc_.grad) < 1e-5
+
+
+@pytest.mark.parametrize("bs,T,ncrops,k,F", [(4, 32, 10, 3, 1024), (32, 32, 10, 3, 1024), (2, 5, 2, 2, 17)])
+def test_mgfn_loss_fwd_bwd_vs_oracle(bs, T, ncrops, k, F):
+    from anomaly_detection_on_video_amd import mil_ops
+    from oracle import mgfn_oracle
+
+    n = bs // 2
+    sc = synth_tensor(f"k10.sc.{bs}", (bs, T, 1), scale=0.45, offset=0.5)
+    sa = synth_tensor(f"k10.sa.{bs}", (n, 1), scale=0.4, offset=0.5)
+    sn = synth_tensor(f"k10.sn.{bs}", (n, 1), scale=0.4, offset=0.5)
+    fa = synth_tensor(f"k10.fa.{bs}", (ncrops * n, k, F), scale=1.0, offset=0.05)
+    fn = synth_tensor(f"k10.fn.{bs}", (ncrops * n, k, F), scale=0.8)
+    al, nl = torch.ones(n), torch.zeros(n)
+    cpu = [t.clone().requires_grad_(True) for t in (sc, sa, sn, fa, fn)]
+    l_mgfn, terms = mgfn_oracle.mgfn_loss(cpu[1], cpu[2], cpu[3], cpu[4], al, nl)
+    total = l_mgfn + mgfn_oracle.smoothness_loss(cpu[0]) + mgfn_oracle.sparsity_loss(cpu[0][: bs // 2].reshape(-1))
+    (total * 1.7).backward()
+    gpu = [t.to(DEV).requires_grad_(True) for t in (sc, sa, sn, fa, fn)]
+    loss, t8 = mil_ops.mgfn_loss(gpu[0], gpu[1], gpu[2], gpu[3], gpu[4], al.to(DEV), nl.to(DEV), ncrops)
+    assert rel_err(loss.detach().cpu(), total.detach()) < 1e-5
+    t8 = t8.cpu()
+    assert rel_err(t8[1], terms["cls"].detach()) < 1e-5
+    assert rel_err(t8[2], terms["con"].detach()) < 1e-5
+    assert rel_err(t8[3], terms["con_a"].detach()) < 1e-5
+    assert rel_err(t8[4], terms["con_n"].detach()) < 1e-5
+    assert rel_err(t8[7], l_mgfn.detach()) < 1e-5
+    (loss * 1.7).backward()
+    for a, b, name in zip(gpu, cpu, ("scores", "abn", "nor", "a_feat", "n_feat")):
+        assert rel_err(a.grad.cpu(), b.grad) < 1e-4, name  # differences of O(500) L1 norms: fp32 cancellation
+
+
+@pytest.mark.parametrize("n", [5, 32, 33, 100, 517])
+def test_segment_features_on_device_bit_exact(n):
+    from anomaly_detection_on_video_amd import mil_ops
+    from oracle import host_oracle
+
+    f = synth_tensor(f"segdev/{n}", (n, 10, 64), scale=3.0)
+    out = mil_ops.segment_features(f.to(DEV), 32).cpu().numpy()
+    np.testing.assert_array_equal(out, host_oracle.segment_features(f.numpy(), 32))
+
+
+def test_segment_features_matches_reference_golden():
+    from anomaly_detection_on_video_amd import mil_ops
+
+    g = np.load(os.path.join(GOLDEN, "host.npz"))
+    for n in (5, 32, 33, 100):
+        f = synth_tensor(f"segment/{n}", (n, 10, 64), scale=3.0)
+        np.testing.assert_array_equal(mil_ops.segment_features(f.to(DEV), 32).cpu().numpy(), g[f"segment_{n}"])
+
+
+def test_add_magnitude_on_device():
+    from anomaly_detection_on_video_amd import mil_ops
+
+    g = np.load(os.path.join(GOLDEN, "host.npz"))
+    f = synth_tensor("addmag", (10, 32, 48), scale=2.0)
+    out = mil_ops.add_magnitude(f.to(DEV)).cpu()
+    assert torch.equal(out[..., :48], f)
+    assert rel_err(out, g["addmag"]) < 1e-6
+
+
+def test_head_refuses_cpu_tensors():
+    from anomaly_detection_on_video_amd import _lib
+    from anomaly_detection_on_video_amd.models.mgfn import MGFNConfig, MGFNForVideoAnomalyDetection
+
+    m = MGFNForVideoAnomalyDetection(MGFNConfig()).eval()
+    with pytest.raises(_lib.HipExtensionError):
+        m(video=mgfn_inputs(1, 8, 0))
