@@ -1,0 +1,103 @@
+"""Feature-extraction driver: the hot loops of `/root/reference/extract_features.py`.
+
+Kept from the reference: `load_feature_extraction_model`, the `(n_clips, 10, 2048)` output layout
+of `_extract` (:77-102), `.npy` per video with skip-if-exists resume (:104-110, :156) and
+`segment()` (:159-185).  Changed on purpose: the ten crops are folded into
+the batch dimension (one backbone forward over (10*B) crop-clips instead of ten forwards of B),
+nothing builds an autograd graph, features stay on the GPU until a whole video is done, and the
+bucket means of `segment()` run on the device.  Video decoding / TenCrop (decord, torchvision)
+are out of scope: sources here are tensors already shaped like `TenCropVideoFrameDataset` items,
+(n_clips, 10, 16, 3, 224, 224) fp32 normalised frames (src/dataset.py:192-195).
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Dict, Iterable, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import dist as adist
+from . import mil_ops
+from .i3d import build_i3d_feature_extractor
+
+FRAMES_PER_CLIP = 16
+NCROPS = 10
+
+
+def load_feature_extraction_model(model_name: str = "tushar-n-baseline", **factory_kwargs):
+    """(model.eval() on the GPU, device) -- extract_features.py:34-40.  The reference defaults to the
+    third-party pytorchvideo variant `i3d_8x8_r50`; the HIP path implements the in-repo I3Res50
+    (`tushar-n-baseline`), which is what the training features (`revision: tushar-n`) come from."""
+    model = build_i3d_feature_extractor(model_name=model_name, **factory_kwargs)
+    model.eval()
+    if not torch.cuda.is_available():
+        raise RuntimeError("no AMD GPU visible: the extraction path runs only as HIP kernels (no CPU fallback)")
+    model.cuda()
+    device = next(model.parameters()).device
+    return model, device
+
+
+@torch.no_grad()
+def extract_clip_batch(model, clips: torch.Tensor, max_crop_clips: int = 40, sharded: bool = False) -> torch.Tensor:
+    """(B, ncrops, 16, 3, H, W) TenCrop'd clips -> (B, ncrops, 2048) features on the device.
+
+    `max_crop_clips` bounds the folded batch per backbone launch (activation memory).  With
+    `sharded=True` the folded crop-clips are split over the ranks of the default process group
+    and the rows all-gathered (dist.sharded_map_rows)."""
+    if clips.dim() != 6:
+        raise ValueError(f"expected (B, ncrops, T, 3, H, W), got {tuple(clips.shape)}")
+    B, ncrops = clips.shape[:2]
+    dev = next(model.parameters()).device
+    # (B, ncrops, T, C, H, W) -> (B*ncrops, C, T, H, W): the reference's permute (:83) + crop fold
+    folded = clips.to(dev, non_blocking=True).permute(0, 1, 3, 2, 4, 5).reshape(B * ncrops, clips.shape[3], clips.shape[2], *clips.shape[4:])
+
+    def run(units: torch.Tensor) -> torch.Tensor:
+        outs = []
+        for i in range(0, units.shape[0], max_crop_clips):
+            outs.append(model(units[i : i + max_crop_clips].contiguous()).reshape(-1, 2048))
+        return torch.cat(outs, dim=0)
+
+    rows = adist.sharded_map_rows(run, folded) if sharded else run(folded)
+    return rows.reshape(B, ncrops, 2048)
+
+
+@torch.no_grad()
+def extract_video(model, video_clips: torch.Tensor, batch_size: int = 16, **kw) -> np.ndarray:
+    """The reference's `_extract`: all clips of one video -> np.float32 (n_clips, 10, 2048)."""
+    outs = [extract_clip_batch(model, video_clips[i : i + batch_size], **kw) for i in range(0, video_clips.shape[0], batch_size)]
+    out = torch.cat(outs, dim=0).cpu().numpy()
+    return np.squeeze(out)  # np.squeeze as the reference does (:100): a 1-clip video loses its first axis
+
+
+def extract(sources: Iterable[Tuple[str, Callable[[], torch.Tensor]]], model, outpath: str, **kw) -> Dict[str, str]:
+    """Per-video driver with the reference's resume rule: skip a video whose `<name>_i3d.npy`
+    exists (:106-110).  `sources` yields (name, loader) where loader() returns the clip tensor."""
+    os.makedirs(outpath, exist_ok=True)
+    written = {}
+    for name, loader in sources:
+        savepath = os.path.join(outpath, name + "_i3d.npy")
+        if os.path.exists(savepath):
+            continue
+        np.save(savepath, extract_video(model, loader(), **kw))
+        written[name] = savepath
+    return written
+
+
+def segment_array(features: np.ndarray, seg_length: int = 32, device: Optional[torch.device] = None) -> np.ndarray:
+    """(n_clips, 10, C) -> (10, seg_length, C) float32, bucket means on the GPU (:171-183)."""
+    dev = device or torch.device("cuda")
+    f = torch.as_tensor(features, dtype=torch.float32).to(dev)
+    return mil_ops.segment_features(f, seg_length).cpu().numpy()
+
+
+def segment(feature_path: str, seg_outpath: str, seg_length: int = 32) -> None:
+    """File driver of extract_features.py:159-185 (same skip-if-exists rule)."""
+    os.makedirs(seg_outpath, exist_ok=True)
+    for file in sorted(os.listdir(feature_path)):
+        if not file.endswith(".npy"):
+            continue
+        savepath = os.path.join(seg_outpath, file)
+        if os.path.exists(savepath):
+            continue
+        np.save(savepath, segment_array(np.load(os.path.join(feature_path, file)), seg_length))

@@ -150,7 +150,11 @@ class I3Res50(nn.Module):
         return out
 
     # ------------------------------------------------------------------ forward
-    def forward_single(self, x: torch.Tensor, taps: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    def forward_single(self, x: torch.Tensor, taps: Optional[Dict[str, torch.Tensor]] = None,
+                       events: Optional[List] = None) -> torch.Tensor:
+        """`taps`: filled with every unit's output (tests).  `events`: if a list, HIP events
+        (recorded on the launch stream) are appended as [start, (pool_start, pool_end) x3, end] so a
+        caller can time the conv stack = (start..end) minus the pool launches (bench.py roofline)."""
         if self.training:
             raise _lib.HipExtensionError(
                 "I3Res50 HIP path implements eval-mode BatchNorm (running statistics) only; call .eval() "
@@ -165,10 +169,25 @@ class I3Res50(nn.Module):
         self.prepare()
         with torch.no_grad():
             x = x.detach().contiguous()
+
+            def mark():
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                events.append(e)
+
+            if events is not None:
+                mark()
             for u in self._plan:
+                pool = events is not None and u.kind in ("maxpool", "avgpool")
+                if pool:
+                    mark()
                 x = u.run(x)
+                if pool:
+                    mark()
                 if taps is not None and u.name:
                     taps[u.name] = x
+            if events is not None:
+                mark()
         return x
 
     def forward(self, batch):

@@ -1,0 +1,65 @@
+"""extract -> MIL score stream: the whole hot path resident on the GPU.
+
+A stream of crop-clips in the reference's order (video-major, clip, crop:
+`(n_clips, 10, 2048)` per video, extract_features.py:93-100) is cut into global batches; every rank
+runs the I3D backbone on its contiguous block, the 2048-d rows are all-gathered (RCCL), written
+into a per-video ring and, whenever a video's last crop-clip has arrived, the rank that owns the
+video scores it: add_magnitude (dataset.py:121-124) -> MGFN eval forward (runner.py:42-50) ->
+clip-level anomaly scores.
+"""
+from __future__ import annotations
+
+from math import gcd
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import dist as adist
+from . import mil_ops
+
+
+class ExtractScoreStream:
+    def __init__(self, backbone, scorer, clips_per_video: int = 32, ncrops: int = 10, local_batch: int = 32,
+                 world: int = 1, rank: int = 0, feat_dim: int = 2048):
+        self.backbone, self.scorer = backbone, scorer
+        self.clips_per_video, self.ncrops = clips_per_video, ncrops
+        self.local_batch, self.world, self.rank = local_batch, world, rank
+        self.per_video = clips_per_video * ncrops
+        self.global_batch = local_batch * world
+        lcm = self.per_video * self.global_batch // gcd(self.per_video, self.global_batch)
+        self.ring_rows = lcm
+        dev = next(backbone.parameters()).device
+        self.ring = torch.zeros((self.ring_rows, feat_dim), device=dev, dtype=torch.float32)
+        self.pos = 0  # global stream position (crop-clips consumed so far)
+        self.videos_scored = 0
+        self.last_scores: Optional[torch.Tensor] = None
+
+    @torch.no_grad()
+    def step(self, local_clips: torch.Tensor) -> Tuple[torch.Tensor, List[Tuple[int, torch.Tensor]]]:
+        """local_clips: this rank's (local_batch, 3, T, H, W) block of the next global batch.
+        Returns (gathered features (global_batch, 2048), [(video index, scores (clips,)) ...])."""
+        feats = self.backbone(local_clips).reshape(local_clips.shape[0], -1)
+        gathered = adist.all_gather_rows(feats) if self.world > 1 else feats
+        start = self.pos % self.ring_rows
+        self.ring[start : start + self.global_batch].copy_(gathered)
+        first_done = self.pos // self.per_video  # videos complete before this batch
+        self.pos += self.global_batch
+        scored = []
+        for v in range(first_done, self.pos // self.per_video):
+            if v % self.world != self.rank:
+                continue
+            r0 = (v * self.per_video) % self.ring_rows
+            vid = self.ring[r0 : r0 + self.per_video].view(self.clips_per_video, self.ncrops, -1)
+            scored.append((v, self.score_video(vid)))
+        return gathered, scored
+
+    @torch.no_grad()
+    def score_video(self, feats: torch.Tensor) -> torch.Tensor:
+        """(n_clips, ncrops, 2048) -> (n_clips,) anomaly scores; validation_step semantics
+        (runner.py:42-50): add magnitude channel, (1, T, 10, 2049) -> (1, 10, T, 2049), eval forward."""
+        x = mil_ops.add_magnitude(feats)  # (T, 10, 2049)
+        video = x.unsqueeze(0).permute(0, 2, 1, 3).contiguous()
+        out = self.scorer(video=video)
+        self.videos_scored += 1
+        self.last_scores = out.scores.reshape(-1)
+        return self.last_scores
