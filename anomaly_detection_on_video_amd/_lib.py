@@ -21,7 +21,18 @@ ALGO_IGEMM_128x128 = 1
 ALGO_IGEMM_128x64 = 2
 ALGO_IGEMM_64x64 = 3
 ALGO_IGEMM_64x128 = 4
+ALGO_IGEMM_128x128x32 = 5
+ALGO_IGEMM_128x64x32 = 6
+ALGO_IGEMM_64x64x32 = 7
+ALGO_IGEMM_64x128x32 = 8
 ALGO_STEM = 16
+IGEMM_ALGOS = (1, 2, 3, 4, 5, 6, 7, 8)
+
+
+def algo_tile(algo: int):
+    """(BM, BN, BK) of an implicit-GEMM algorithm id."""
+    t = (algo - 1) & 3
+    return (128 if t in (0, 1) else 64, 128 if t in (0, 3) else 64, 32 if algo >= 5 else 16)
 
 
 class HipExtensionError(RuntimeError):
@@ -31,7 +42,7 @@ class HipExtensionError(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "B", "Cin", "T", "H", "W", "Cout", "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw",
-        "relu", "algo", "reserved")]
+        "relu", "algo", "splits")]
 
 
 _P = C.c_void_p
@@ -48,7 +59,8 @@ SIGNATURES = {
     "advhip_conv3d_pack_weight_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P]),
     "advhip_conv3d_build_ktab": (C.c_int, [C.POINTER(ConvDesc), _P, _P]),
     "advhip_bn_fold_f32": (C.c_int, [_P, _P, _P, _P, C.c_float, _I, _P, _P, _P]),
-    "advhip_conv3d_bn_act_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "advhip_conv3d_workspace_bytes": (_L, [C.POINTER(ConvDesc)]),
+    "advhip_conv3d_bn_act_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "advhip_maxpool3d_f32": (C.c_int, [_P, _P] + [_I] * 11 + [_P]),
     "advhip_global_avgpool_f32": (C.c_int, [_P, _P, _L, _I, _P]),
     "advhip_mil_magnitude_f32": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -32,7 +32,7 @@ struct ConvArgs {
   const float* scale;
   const float* shift;
   const float* res;   // nullable, same shape as y
-  float* y;
+  float* y;           // output, or the split-K partial slabs [splits][B*Cout*THWo]
   int B, Cin, T, H, W, Cout;
   int st, sh, sw, pt, ph, pw;
   int To, Ho, Wo;
@@ -40,6 +40,8 @@ struct ConvArgs {
   int THWo, HWo, HW, THW;
   int tiles_m, tiles_n;
   int relu, vw;
+  int splits;         // 1 = fused epilogue; >1 = raw partial sums, reduced by splitk_reduce_kernel
+  long long slab;     // elements per split-K slab
 };
 
 template <int VW>
@@ -65,23 +67,44 @@ __device__ __forceinline__ void vec_store(float* p, const float (&v)[VW]) {
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
+struct IgemmCfg {
+  static constexpr int FM = BM / 32, FN = BN / 32;  // 16x16 fragments per wave along M / N
+  static constexpr int WM = BM / 2, WN = BN / 2;    // wave tile (2 x 2 waves)
+  static constexpr int KR = 256 / BM;               // k-rows covered by one pass of the 256 threads
+  static constexpr int RA = BK / KR;                // A elements gathered per thread per k-tile
+  static constexpr int RB = BK * BN / 4 / 256;      // float4 of B per thread per k-tile
+  static constexpr int AB_FLOATS = 2 * BK * (BM + BN);
+  static constexpr int ST_STRIDE = WM + 4;          // epilogue staging row (floats), 16-B multiple
+  static constexpr int ST_FLOATS = 4 * 16 * ST_STRIDE;
+  static constexpr int SMEM_FLOATS = AB_FLOATS > ST_FLOATS ? AB_FLOATS : ST_FLOATS;
+};
+
+template <int BM, int BN, int BK>
 __global__ __launch_bounds__(256) void conv3d_igemm_f32_kernel(const ConvArgs a) {
-  constexpr int BK = 16;
-  constexpr int FM = BM / 32, FN = BN / 32;  // 16x16 fragments per wave along M / N
-  constexpr int KR = 256 / BM;               // k-rows covered by one pass of the 256 threads
-  constexpr int RA = BK / KR;                // A elements gathered per thread per k-tile
-  constexpr int RB = BK * BN / 4 / 256;      // float4 of B per thread per k-tile
+  using Cfg = IgemmCfg<BM, BN, BK>;
+  constexpr int FM = Cfg::FM, FN = Cfg::FN, KR = Cfg::KR, RA = Cfg::RA, RB = Cfg::RB;
   static_assert(FM == 4 || FM == 2, "wave M tile must be 64 or 32");
   static_assert(FN == 4 || FN == 2, "wave N tile must be 64 or 32");
+  static_assert(RA >= 1 && RB >= 1, "tile too small for 256 threads");
 
-  __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+  __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM_FLOATS];
+  float(*As)[BK][BM] = reinterpret_cast<float(*)[BK][BM]>(smem);
+  float(*Bs)[BK][BN] = reinterpret_cast<float(*)[BK][BN]>(smem + 2 * BK * BM);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int L = xcd_remap(blockIdx.x, a.tiles_m * a.tiles_n);
+  const int ntiles = a.tiles_m * a.tiles_n;
+  int L, split;
+  if (a.splits > 1) {
+    // blocks b and b+8 share an XCD: keep one K-slice of the weights per XCD's L2
+    split = blockIdx.x % a.splits;
+    L = blockIdx.x / a.splits;
+  } else {
+    split = 0;
+    L = xcd_remap(blockIdx.x, ntiles);
+  }
   const int tile_n = L % a.tiles_n, tile_m = L / a.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -136,8 +159,8 @@ __global__ __launch_bounds__(256) void conv3d_igemm_f32_kernel(const ConvArgs a)
   // ---- MFMA main loop ---------------------------------------------------------------------
   const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves
   const int li = lane & 15, lg = lane >> 4;
-  const int a_col = wm * (BM / 2) + FM * li;
-  const int b_col = wn * (BN / 2) + FN * li;
+  const int a_col = wm * Cfg::WM + FM * li;
+  const int b_col = wn * Cfg::WN + FN * li;
 
   f32x4 acc[FM][FN];
 #pragma unroll
@@ -145,13 +168,18 @@ __global__ __launch_bounds__(256) void conv3d_igemm_f32_kernel(const ConvArgs a)
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = a.Kpad / BK;
-  load_tiles(0);
-  store_tiles(0);
+  // k-tiles of this split: [kt0, kt1)
+  const int nk_all = a.Kpad / BK;
+  const int kt0 = (int)((long long)nk_all * split / a.splits);
+  const int kt1 = (int)((long long)nk_all * (split + 1) / a.splits);
+  if (kt0 < kt1) {
+    load_tiles(kt0 * BK);
+    store_tiles(0);
+  }
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    if (kt + 1 < kt1) load_tiles((kt + 1) * BK);
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
       float av[FM], bv[FN];
@@ -175,14 +203,77 @@ __global__ __launch_bounds__(256) void conv3d_igemm_f32_kernel(const ConvArgs a)
         for (int j = 0; j < FN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_tiles(cur ^ 1);
+    if (kt + 1 < kt1) store_tiles(cur ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue: scale/shift (+res) (+relu), NCDHW store ------------------------------------
+  // ---- epilogue ---------------------------------------------------------------------------
   // accumulator element acc[jm][jn][r] of lane (li, lg):
-  //   m = m0 + wm*BM/2 + FM*(4*lg + r) + jm,   n = n0 + wn*BN/2 + FN*li + jn
-  const int m_lane = m0 + wm * (BM / 2) + FM * 4 * lg;  // first of FM*4 consecutive m
+  //   m = m0 + wm*WM + FM*(4*lg + r) + jm,   n = n0 + wn*WN + FN*li + jn
+  const bool fused = a.splits == 1;
+  float* __restrict__ yout = a.y + (size_t)split * a.slab;
+  if (a.vw == 4) {
+    // Coalesced path (THWo % 4 == 0): each wave transposes its tile through LDS, one fragment
+    // column (16 channels x WM positions) at a time, so that global stores / residual loads are
+    // whole 16-byte pieces of contiguous NCDHW rows (WM*4 bytes per channel per wave).
+    float* st = smem + wave * (16 * Cfg::ST_STRIDE);
+    constexpr int LPR = Cfg::WM / 4;      // lanes per staged row (16 or 8)
+    constexpr int RPI = 64 / LPR;         // rows per read instruction (4 or 8)
+    const int rrow = lane / LPR, rcol = (lane % LPR) * 4;
+    const int mm = m0 + wm * Cfg::WM + rcol;  // this lane's 4 consecutive m in the read phase
+    const bool mok = mm < a.M;                // M % 4 == 0 here, so the group is all-in or all-out
+    int bb = 0, pp = 0;
+    if (mok) { bb = mm / a.THWo; pp = mm - bb * a.THWo; }
+#pragma unroll
+    for (int jn = 0; jn < FN; ++jn) {
+      // write phase: 4*FM consecutive m per lane for channel row li
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if constexpr (FM == 4) {
+          *reinterpret_cast<float4*>(&st[li * Cfg::ST_STRIDE + 16 * lg + 4 * r]) =
+              make_float4(acc[0][jn][r], acc[1][jn][r], acc[2][jn][r], acc[3][jn][r]);
+        } else {
+          *reinterpret_cast<float2*>(&st[li * Cfg::ST_STRIDE + 8 * lg + 2 * r]) = make_float2(acc[0][jn][r], acc[1][jn][r]);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int i = 0; i < 16 / RPI; ++i) {
+        const int row = rrow + RPI * i;  // channel row within the fragment column
+        float v[4];
+        vec_load<4>(&st[row * Cfg::ST_STRIDE + rcol], v);
+        if (mok) {
+          const int n = n0 + wn * Cfg::WN + FN * row + jn;
+          const size_t o = (size_t)(bb * a.Cout + n) * a.THWo + pp;
+          if (fused) {
+            const float sc = a.scale[n], sf = a.shift[n];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * sc + sf;
+            if (a.res) {
+              float rv[4];
+              vec_load<4>(a.res + o, rv);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += rv[e];
+            }
+            if (a.relu) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+          }
+          vec_store<4>(yout + o, v);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    return;
+  }
+  // Generic path (THWo not a multiple of 4: rows of consecutive m may straddle a sample): direct
+  // per-lane stores of VW consecutive m.
+  const int m_lane = m0 + wm * Cfg::WM + FM * 4 * lg;  // first of FM*4 consecutive m
   const int n_lane = n0 + b_col;
   auto emit = [&](auto vw_tag) {
     constexpr int VW = decltype(vw_tag)::value;  // divides FM and THWo
@@ -197,33 +288,69 @@ __global__ __launch_bounds__(256) void conv3d_igemm_f32_kernel(const ConvArgs a)
 #pragma unroll
         for (int jn = 0; jn < FN; ++jn) {
           const int n = n_lane + jn;
-          const float sc = a.scale[n], sf = a.shift[n];
           const size_t o = (size_t)(bb * a.Cout + n) * a.THWo + pp;
           float vals[VW];
 #pragma unroll
-          for (int e = 0; e < VW; ++e) vals[e] = acc[v0 + e][jn][r] * sc + sf;
-          if (a.res) {
-            float rv[VW];
-            vec_load<VW>(a.res + o, rv);
+          for (int e = 0; e < VW; ++e) vals[e] = acc[v0 + e][jn][r];
+          if (fused) {
+            const float sc = a.scale[n], sf = a.shift[n];
 #pragma unroll
-            for (int e = 0; e < VW; ++e) vals[e] += rv[e];
-          }
-          if (a.relu) {
+            for (int e = 0; e < VW; ++e) vals[e] = vals[e] * sc + sf;
+            if (a.res) {
+              float rv[VW];
+              vec_load<VW>(a.res + o, rv);
 #pragma unroll
-            for (int e = 0; e < VW; ++e) vals[e] = fmaxf(vals[e], 0.f);
+              for (int e = 0; e < VW; ++e) vals[e] += rv[e];
+            }
+            if (a.relu) {
+#pragma unroll
+              for (int e = 0; e < VW; ++e) vals[e] = fmaxf(vals[e], 0.f);
+            }
           }
-          vec_store<VW>(a.y + o, vals);
+          vec_store<VW>(yout + o, vals);
         }
       }
     }
   };
-  if constexpr (FM == 4) {
-    if (a.vw == 4) emit(std::integral_constant<int, 4>{});
-    else if (a.vw == 2) emit(std::integral_constant<int, 2>{});
-    else emit(std::integral_constant<int, 1>{});
+  if (a.vw == 2) emit(std::integral_constant<int, 2>{});
+  else emit(std::integral_constant<int, 1>{});
+}
+
+// y = act(sum_s slab[s] * scale[c] + shift[c] (+ res)), slabs in NCDHW like y
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, const float* __restrict__ res,
+                                     float* __restrict__ y, long long total, int THWo, int Cout, int splits, int relu,
+                                     int vec4) {
+  if (vec4) {
+    const long long n4 = total / 4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
+         i += (long long)gridDim.x * blockDim.x) {
+      float4 s = reinterpret_cast<const float4*>(ws)[i];
+      for (int k = 1; k < splits; ++k) {
+        const float4 t = reinterpret_cast<const float4*>(ws + (size_t)k * total)[i];
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+      const int c = (int)((i * 4 / THWo) % Cout);
+      const float sc = scale[c], sf = shift[c];
+      float4 o = make_float4(s.x * sc + sf, s.y * sc + sf, s.z * sc + sf, s.w * sc + sf);
+      if (res) {
+        const float4 r = reinterpret_cast<const float4*>(res)[i];
+        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+      }
+      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      reinterpret_cast<float4*>(y)[i] = o;
+    }
   } else {
-    if (a.vw >= 2) emit(std::integral_constant<int, 2>{});
-    else emit(std::integral_constant<int, 1>{});
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+      float s = ws[i];
+      for (int k = 1; k < splits; ++k) s += ws[(size_t)k * total + i];
+      const int c = (int)((i / THWo) % Cout);
+      float o = s * scale[c] + shift[c];
+      if (res) o += res[i];
+      if (relu) o = fmaxf(o, 0.f);
+      y[i] = o;
+    }
   }
 }
 
@@ -292,7 +419,7 @@ extern "C" int advhip_conv3d_out_dims(const advhip_conv3d_desc* d, int32_t* To, 
 extern "C" int advhip_conv3d_packed_rows(const advhip_conv3d_desc* d) {
   if (int rc = validate(d)) return rc;
   const int K = d->Cin * d->kt * d->kh * d->kw;
-  return (K + 15) / 16 * 16;
+  return (K + 31) / 32 * 32;
 }
 
 extern "C" int advhip_conv3d_pack_weight_f32(const advhip_conv3d_desc* d, const float* w, float* w_packed,
@@ -300,7 +427,7 @@ extern "C" int advhip_conv3d_pack_weight_f32(const advhip_conv3d_desc* d, const 
   if (int rc = validate(d)) return rc;
   ADVHIP_REQUIRE(w && w_packed, "pack_weight: null pointer");
   const int K = d->Cin * d->kt * d->kh * d->kw;
-  const int Kpad = (K + 15) / 16 * 16;
+  const int Kpad = (K + 31) / 32 * 32;
   const long long total = (long long)Kpad * d->Cout;
   const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
   hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, w_packed, d->Cout, K, Kpad);
@@ -311,7 +438,7 @@ extern "C" int advhip_conv3d_build_ktab(const advhip_conv3d_desc* d, int32_t* kt
   if (int rc = validate(d)) return rc;
   ADVHIP_REQUIRE(ktab, "build_ktab: null pointer");
   const int K = d->Cin * d->kt * d->kh * d->kw;
-  const int Kpad = (K + 15) / 16 * 16;
+  const int Kpad = (K + 31) / 32 * 32;
   hipLaunchKernelGGL(build_ktab_kernel, dim3((Kpad + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<int4*>(ktab), d->kt, d->kh, d->kw, K, Kpad, d->H * d->W, d->W,
                      d->T * d->H * d->W);
@@ -329,63 +456,145 @@ extern "C" int advhip_bn_fold_f32(const float* gamma, const float* beta, const f
 namespace advhip {
 int launch_stem(const advhip_conv3d_desc* d, const float* x, const float* w_packed, const float* scale,
                 const float* shift, float* y, hipStream_t stream);  // conv_stem.hip
+
+struct Choice {
+  int algo;    // ADVHIP_ALGO_IGEMM_*
+  int splits;  // >= 1
+};
+
+static void tile_of(int algo, int* BM, int* BN, int* BK) {
+  const int t = (algo - 1) & 3;
+  *BM = (t == 0 || t == 1) ? 128 : 64;
+  *BN = (t == 0 || t == 3) ? 128 : 64;
+  *BK = algo >= ADVHIP_ALGO_IGEMM_128x128x32 ? 32 : 16;
+}
+
+// Heuristic used when the caller does not pin algo/splits (the Python engine normally pins both
+// from a measured table).  Goal: >= ~3 workgroups per CU; big tiles when M*N is plentiful, split-K
+// when it is not and K is long.
+static Choice choose(const advhip_conv3d_desc* d, long long M, int Kpad) {
+  Choice c{d->algo, d->splits};
+  const int N = d->Cout;
+  if (c.algo == ADVHIP_ALGO_AUTO) {
+    const long long t128 = (M + 127) / 128, t64 = (M + 63) / 64;
+    const bool n128 = N % 128 == 0;
+    if (n128 && t128 * (N / 128) >= 1024) c.algo = ADVHIP_ALGO_IGEMM_128x128;
+    else if (t128 * (N / 64) >= 1024) c.algo = ADVHIP_ALGO_IGEMM_128x64;
+    else if (n128 && t64 * (N / 128) >= 768) c.algo = ADVHIP_ALGO_IGEMM_64x128;
+    else if (t64 * (N / 64) >= 768) c.algo = ADVHIP_ALGO_IGEMM_64x64;
+    else c.algo = n128 ? ADVHIP_ALGO_IGEMM_128x128x32 : ADVHIP_ALGO_IGEMM_128x64x32;  // + split-K below
+  }
+  if (c.splits <= 0) {
+    int BM, BN, BK;
+    tile_of(c.algo, &BM, &BN, &BK);
+    const long long tiles = ((M + BM - 1) / BM) * (N / BN);
+    const int nk = Kpad / BK;
+    int s = 1;
+    while (tiles * s < 768 && s < 8 && nk / (s * 2) >= 8) s *= 2;
+    c.splits = s;
+  }
+  return c;
+}
+
+struct Geometry {
+  int To, Ho, Wo;
+  long long M;
+  int K, Kpad;
+};
+static Geometry geometry(const advhip_conv3d_desc* d) {
+  Geometry g;
+  g.To = out_dim(d->T, d->kt, d->st, d->pt);
+  g.Ho = out_dim(d->H, d->kh, d->sh, d->ph);
+  g.Wo = out_dim(d->W, d->kw, d->sw, d->pw);
+  g.M = (long long)d->B * g.To * g.Ho * g.Wo;
+  g.K = d->Cin * d->kt * d->kh * d->kw;
+  g.Kpad = (g.K + 31) / 32 * 32;
+  return g;
+}
+}  // namespace advhip
+
+extern "C" int64_t advhip_conv3d_workspace_bytes(const advhip_conv3d_desc* d) {
+  if (validate(d)) return -1;
+  if (d->algo == ADVHIP_ALGO_STEM) return 0;
+  const Geometry g = geometry(d);
+  const Choice c = choose(d, g.M, g.Kpad);
+  return c.splits > 1 ? (int64_t)c.splits * g.M * d->Cout * (int64_t)sizeof(float) : 0;
 }
 
 extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float* x, const float* w_packed,
                                         const int32_t* ktab, const float* scale, const float* shift,
-                                        const float* residual, float* y, void* stream) {
+                                        const float* residual, float* y, void* workspace, int64_t workspace_bytes,
+                                        void* stream) {
   if (int rc = validate(d)) return rc;
   ADVHIP_REQUIRE(x && w_packed && ktab && scale && shift && y, "conv3d: null pointer");
+  const Geometry g = geometry(d);
   ConvArgs a;
   a.x = x; a.w = w_packed; a.ktab = reinterpret_cast<const int4*>(ktab);
   a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
   a.B = d->B; a.Cin = d->Cin; a.T = d->T; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
   a.st = d->st; a.sh = d->sh; a.sw = d->sw; a.pt = d->pt; a.ph = d->ph; a.pw = d->pw;
-  a.To = out_dim(d->T, d->kt, d->st, d->pt);
-  a.Ho = out_dim(d->H, d->kh, d->sh, d->ph);
-  a.Wo = out_dim(d->W, d->kw, d->sw, d->pw);
+  a.To = g.To; a.Ho = g.Ho; a.Wo = g.Wo;
   const long long in_elems = (long long)d->B * d->Cin * d->T * d->H * d->W;
-  const long long M = (long long)d->B * a.To * a.Ho * a.Wo;
+  const long long M = g.M;
   if (in_elems >= (1ll << 31) || M * d->Cout >= (1ll << 32) || M >= (1ll << 31)) {
     set_error("conv3d: tensor too large for 32-bit indexing (in=%lld, out=%lld elements)", in_elems, M * d->Cout);
     return ADVHIP_ERANGE;
   }
   a.M = (int)M;
-  const int K = d->Cin * d->kt * d->kh * d->kw;
-  a.Kpad = (K + 15) / 16 * 16;
+  a.Kpad = g.Kpad;
   a.HWo = a.Ho * a.Wo; a.THWo = a.To * a.HWo;
   a.HW = d->H * d->W; a.THW = d->T * a.HW;
   a.relu = d->relu;
   a.vw = (a.THWo % 4 == 0) ? 4 : (a.THWo % 2 == 0 ? 2 : 1);
 
-  int algo = d->algo;
-  if (algo == ADVHIP_ALGO_STEM) {
+  if (d->algo == ADVHIP_ALGO_STEM) {
     ADVHIP_REQUIRE(residual == nullptr, "conv3d: stem kernel takes no residual");
     return launch_stem(d, x, w_packed, scale, shift, y, (hipStream_t)stream);
   }
-  if (algo == ADVHIP_ALGO_AUTO) {
-    // Fill the 256 CUs: prefer the biggest tile that still yields >= 4 workgroups per CU.
-    const long long t128 = (M + 127) / 128, t64 = (M + 63) / 64;
-    const bool n128 = d->Cout % 128 == 0;
-    if (n128 && t128 * (d->Cout / 128) >= 1024) algo = ADVHIP_ALGO_IGEMM_128x128;
-    else if (t128 * (d->Cout / 64) >= 1024) algo = ADVHIP_ALGO_IGEMM_128x64;
-    else if (n128 && t64 * (d->Cout / 128) >= 768) algo = ADVHIP_ALGO_IGEMM_64x128;
-    else algo = ADVHIP_ALGO_IGEMM_64x64;
+  const Choice c = choose(d, M, g.Kpad);
+  int BM, BN, BK;
+  tile_of(c.algo, &BM, &BN, &BK);
+  ADVHIP_REQUIRE(c.algo >= ADVHIP_ALGO_IGEMM_128x128 && c.algo <= ADVHIP_ALGO_IGEMM_64x128x32, "conv3d: unknown algo %d", c.algo);
+  ADVHIP_REQUIRE(d->Cout % BN == 0, "conv3d: Cout=%d not a multiple of the %d-wide N tile", d->Cout, BN);
+  ADVHIP_REQUIRE(g.Kpad % BK == 0 || BK == 16, "conv3d: internal: Kpad");
+  a.splits = c.splits;
+  a.slab = M * d->Cout;
+  const int nk = (g.Kpad + BK - 1) / BK;
+  ADVHIP_REQUIRE(c.splits >= 1 && c.splits <= nk && c.splits <= 64, "conv3d: bad split count %d (k-tiles %d)", c.splits, nk);
+  if (c.splits > 1) {
+    const int64_t need = (int64_t)c.splits * a.slab * (int64_t)sizeof(float);
+    ADVHIP_REQUIRE(workspace != nullptr && workspace_bytes >= need,
+                   "conv3d: split-K needs a %lld-byte workspace (got %lld); query advhip_conv3d_workspace_bytes",
+                   (long long)need, (long long)workspace_bytes);
+    a.y = reinterpret_cast<float*>(workspace);
   }
-  auto launch = [&](auto kern, int BM, int BN) -> int {
-    ADVHIP_REQUIRE(d->Cout % BN == 0, "conv3d: Cout=%d not a multiple of the %d-wide N tile", d->Cout, BN);
-    a.tiles_m = (int)((M + BM - 1) / BM);
-    a.tiles_n = d->Cout / BN;
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), 0, (hipStream_t)stream, a);
-    return check_launch("conv3d_igemm");
-  };
-  switch (algo) {
-    case ADVHIP_ALGO_IGEMM_128x128: return launch(conv3d_igemm_f32_kernel<128, 128>, 128, 128);
-    case ADVHIP_ALGO_IGEMM_128x64: return launch(conv3d_igemm_f32_kernel<128, 64>, 128, 64);
-    case ADVHIP_ALGO_IGEMM_64x64: return launch(conv3d_igemm_f32_kernel<64, 64>, 64, 64);
-    case ADVHIP_ALGO_IGEMM_64x128: return launch(conv3d_igemm_f32_kernel<64, 128>, 64, 128);
+  a.tiles_m = (int)((M + BM - 1) / BM);
+  a.tiles_n = d->Cout / BN;
+  const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * c.splits));
+  hipStream_t st = (hipStream_t)stream;
+  // BK = 32 needs Kpad % 32 == 0: the packed weights are padded to 16 rows only, but the k-table
+  // marks rows >= K invalid and the weight rows read beyond Kpad must exist -> require it.
+  if (BK == 32) ADVHIP_REQUIRE(g.Kpad % 32 == 0, "conv3d: BK=32 variants need K padded to 32 (K=%d)", g.K);
+  switch (c.algo) {
+    case ADVHIP_ALGO_IGEMM_128x128: hipLaunchKernelGGL((conv3d_igemm_f32_kernel<128, 128, 16>), grid, dim3(256), 0, st, a); break;
+    case ADVHIP_ALGO_IGEMM_128x64: hipLaunchKernelGGL((conv3d_igemm_f32_kernel<128, 64, 16>), grid, dim3(256), 0, st, a); break;
+    case ADVHIP_ALGO_IGEMM_64x64: hipLaunchKernelGGL((conv3d_igemm_f32_kernel<64, 64, 16>), grid, dim3(256), 0, st, a); break;
+    case ADVHIP_ALGO_IGEMM_64x128: hipLaunchKernelGGL((conv3d_igemm_f32_kernel<64, 128, 16>), grid, dim3(256), 0, st, a); break;
+    case ADVHIP_ALGO_IGEMM_128x128x32: hipLaunchKernelGGL((conv3d_igemm_f32_kernel<128, 128, 32>), grid, dim3(256), 0, st, a); break;
+    case ADVHIP_ALGO_IGEMM_128x64x32: hipLaunchKernelGGL((conv3d_igemm_f32_kernel<128, 64, 32>), grid, dim3(256), 0, st, a); break;
+    case ADVHIP_ALGO_IGEMM_64x64x32: hipLaunchKernelGGL((conv3d_igemm_f32_kernel<64, 64, 32>), grid, dim3(256), 0, st, a); break;
+    case ADVHIP_ALGO_IGEMM_64x128x32: hipLaunchKernelGGL((conv3d_igemm_f32_kernel<64, 128, 32>), grid, dim3(256), 0, st, a); break;
     default: break;
   }
-  set_error("conv3d: unknown algo %d", algo);
-  return ADVHIP_EINVAL;
+  if (int rc = check_launch("conv3d_igemm")) return rc;
+  if (c.splits > 1) {
+    const long long total = a.slab;
+    const int vec4 = (total % 4 == 0 && a.THWo % 4 == 0) ? 1 : 0;
+    const long long work = vec4 ? total / 4 : total;
+    const int rgrid = (int)std::min<long long>((work + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rgrid), dim3(256), 0, st, reinterpret_cast<const float*>(workspace), scale,
+                       shift, residual, y, total, a.THWo, d->Cout, c.splits, d->relu, vec4);
+    return check_launch("splitk_reduce");
+  }
+  return ADVHIP_OK;
 }

@@ -42,13 +42,27 @@ class PackedConv:
     ktabs: Dict[Tuple[int, int, int], torch.Tensor] = field(default_factory=dict)
     algo: int = _lib.ALGO_AUTO
     name: str = ""
+    splits: int = 0  # 0 = library heuristic
+    # (B,T,H,W) -> (algo, splits) resolved from the measured table (tuned.py)
+    choices: Dict[Tuple[int, int, int, int], Tuple[int, int]] = field(default_factory=dict)
 
-    def desc(self, B: int, T: int, H: int, W: int, relu: bool, algo: Optional[int] = None) -> ConvDesc:
+    def key(self, B: int, T: int, H: int, W: int) -> str:
+        return ",".join(str(v) for v in (self.cin, self.cout, *self.kernel, *self.stride, *self.padding, B, T, H, W))
+
+    def desc(self, B: int, T: int, H: int, W: int, relu: bool, algo: Optional[int] = None,
+             splits: Optional[int] = None) -> ConvDesc:
         kt, kh, kw = self.kernel
         st, sh, sw = self.stride
         pt, ph, pw = self.padding
+        if algo is None and splits is None:
+            ch = self.choices.get((B, T, H, W))
+            if ch is None:
+                from . import tuned
+
+                ch = self.choices[(B, T, H, W)] = tuned.lookup(self.key(B, T, H, W), (self.algo, self.splits))
+            algo, splits = ch
         return ConvDesc(B, self.cin, T, H, W, self.cout, kt, kh, kw, st, sh, sw, pt, ph, pw, int(relu),
-                        self.algo if algo is None else algo, 0)
+                        self.algo if algo is None else algo, self.splits if splits is None else splits)
 
 
 def bn_fold(gamma, beta, mean, var, eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -91,8 +105,21 @@ def pack_conv(weight: torch.Tensor, gamma, beta, mean, var, eps: float, stride, 
     return pc
 
 
+_WORKSPACES: Dict[torch.device, torch.Tensor] = {}
+
+
+def workspace(dev: torch.device, nbytes: int) -> Optional[torch.Tensor]:
+    """Grow-only per-device scratch for the split-K partial slabs (caller-owned, per the C ABI)."""
+    if nbytes <= 0:
+        return None
+    ws = _WORKSPACES.get(dev)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = _WORKSPACES[dev] = torch.empty(((nbytes + 3) // 4,), device=dev, dtype=torch.float32)
+    return ws
+
+
 def conv3d_bn_act(x: torch.Tensor, pc: PackedConv, relu: bool = True, residual: Optional[torch.Tensor] = None,
-                  algo: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  algo: Optional[int] = None, out: Optional[torch.Tensor] = None, splits: Optional[int] = None) -> torch.Tensor:
     """act(conv3d(x) * scale + shift (+ residual)) in one fused HIP launch."""
     require_gpu(x, residual)
     if x.dim() != 5 or x.shape[1] != pc.cin:
@@ -108,10 +135,16 @@ def conv3d_bn_act(x: torch.Tensor, pc: PackedConv, relu: bool = True, residual: 
     ktab = pc.ktabs.get(key)
     if ktab is None:
         ktab = pc.ktabs[key] = _build_ktab(pc, key)
-    d = pc.desc(B, T, H, W, relu, algo)
+    if algo is not None and splits is None:
+        splits = 1  # an explicitly pinned tile runs unsplit unless the caller also pins the split
+    d = pc.desc(B, T, H, W, relu, algo, splits)
     lib = _lib.load()
+    need = lib.advhip_conv3d_workspace_bytes(C.byref(d))
+    if need < 0:
+        check(int(need), f"conv3d_workspace_bytes[{pc.name}]")
+    ws = workspace(x.device, need)
     check(lib.advhip_conv3d_bn_act_f32(C.byref(d), ptr(x), ptr(pc.w_packed), ptr(ktab), ptr(pc.scale), ptr(pc.shift),
-                                       ptr(residual), ptr(y), stream()), f"conv3d[{pc.name}]")
+                                       ptr(residual), ptr(y), ptr(ws), need, stream()), f"conv3d[{pc.name}]")
     return y
 
 

@@ -1,0 +1,24 @@
+"""Measured (algorithm, split-K) choices per conv shape, produced by tools/tune_convs.py on an
+MI355X and committed as tuned/gfx950.json.  Unknown shapes fall back to the library heuristic."""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, Optional, Tuple
+
+_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gfx950.json")
+_TABLE: Optional[Dict[str, Tuple[int, int]]] = None
+
+
+def table() -> Dict[str, Tuple[int, int]]:
+    global _TABLE
+    if _TABLE is None:
+        _TABLE = {}
+        if os.environ.get("ADV_NO_TUNED") != "1" and os.path.exists(_PATH):
+            with open(_PATH) as f:
+                _TABLE = {k: (int(v[0]), int(v[1])) for k, v in json.load(f).items()}
+    return _TABLE
+
+
+def lookup(key: str, default: Tuple[int, int]) -> Tuple[int, int]:
+    return table().get(key, default)

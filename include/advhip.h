@@ -38,6 +38,10 @@ extern "C" {
 #define ADVHIP_ALGO_IGEMM_128x64 2
 #define ADVHIP_ALGO_IGEMM_64x64 3
 #define ADVHIP_ALGO_IGEMM_64x128 4
+#define ADVHIP_ALGO_IGEMM_128x128x32 5 /* same tiles, 32-deep k-tile (longer MFMA run per barrier) */
+#define ADVHIP_ALGO_IGEMM_128x64x32 6
+#define ADVHIP_ALGO_IGEMM_64x64x32 7
+#define ADVHIP_ALGO_IGEMM_64x128x32 8
 #define ADVHIP_ALGO_STEM 16 /* dedicated Cin=3 k(5,7,7) s2 kernel, LDS halo tile */
 
 typedef struct advhip_conv3d_desc {
@@ -47,7 +51,7 @@ typedef struct advhip_conv3d_desc {
   int32_t pt, ph, pw;         /* zero padding */
   int32_t relu;               /* apply max(0,.) last */
   int32_t algo;               /* ADVHIP_ALGO_* */
-  int32_t reserved;
+  int32_t splits;             /* split-K factor: 0 = heuristic, 1 = none, n = n K-slices + reduce pass */
 } advhip_conv3d_desc;
 
 /* --- library ------------------------------------------------------------------------------ */
@@ -60,7 +64,7 @@ const char* advhip_target_arch(void);
  * Output extents of a conv / pool (floor mode), the torch formula. */
 int advhip_conv3d_out_dims(const advhip_conv3d_desc* d, int32_t* To, int32_t* Ho, int32_t* Wo);
 
-/* Rows of the packed weight matrix: K = Cin*kt*kh*kw rounded up to a multiple of 16. */
+/* Rows of the packed weight matrix: K = Cin*kt*kh*kw rounded up to a multiple of 32. */
 int advhip_conv3d_packed_rows(const advhip_conv3d_desc* d);
 
 /* Pack torch-layout weights w[Cout][Cin][kt][kh][kw] into the kernels' [Kpad][Cout] layout
@@ -84,10 +88,15 @@ int advhip_bn_fold_f32(const float* gamma, const float* beta, const float* mean,
  * Replaces the nn.Conv3d -> nn.BatchNorm3d -> (+=residual) -> nn.ReLU module sequences of
  * Bottleneck.forward (src/i3d.py:98-121), the stem (src/i3d.py:303-305) and the downsample
  * branch (src/i3d.py:262-272).  `residual` may be NULL; otherwise it has y's shape.
- * fp32 MFMA (v_mfma_f32_16x16x4_f32): exact fp32 products, fp32 accumulation. */
+ * fp32 MFMA (v_mfma_f32_16x16x4_f32): exact fp32 products, fp32 accumulation.
+ * `workspace`: caller-owned device scratch of at least advhip_conv3d_workspace_bytes(d) bytes
+ * (0 unless the (pinned or heuristic) configuration uses split-K: partial-sum slabs that a second
+ * launch reduces in a fixed order, so results stay run-to-run bit-identical). */
+int64_t advhip_conv3d_workspace_bytes(const advhip_conv3d_desc* d);
 int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float* x, const float* w_packed,
                              const int32_t* ktab, const float* scale, const float* shift,
-                             const float* residual, float* y, void* stream);
+                             const float* residual, float* y, void* workspace,
+                             int64_t workspace_bytes, void* stream);
 
 /* nn.MaxPool3d with zero padding=0, floor mode (src/i3d.py:212-217, 306, 309). */
 int advhip_maxpool3d_f32(const float* x, float* y, int32_t B, int32_t C, int32_t T, int32_t H,
