@@ -26,11 +26,15 @@ ALGO_IGEMM_128x64x32 = 6
 ALGO_IGEMM_64x64x32 = 7
 ALGO_IGEMM_64x128x32 = 8
 ALGO_STEM = 16
+ALGO_FAST_BASE = 32  # + tile id: scalar-offset / tap-mask gather (<= 32 taps)
 IGEMM_ALGOS = (1, 2, 3, 4, 5, 6, 7, 8)
+FAST_ALGOS = tuple(ALGO_FAST_BASE + a for a in IGEMM_ALGOS)
 
 
 def algo_tile(algo: int):
     """(BM, BN, BK) of an implicit-GEMM algorithm id."""
+    if algo >= ALGO_FAST_BASE:
+        algo -= ALGO_FAST_BASE
     t = (algo - 1) & 3
     return (128 if t in (0, 1) else 64, 128 if t in (0, 3) else 64, 32 if algo >= 5 else 16)
 

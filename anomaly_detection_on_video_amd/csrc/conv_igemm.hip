@@ -42,6 +42,10 @@ struct ConvArgs {
   int relu, vw;
   int splits;         // 1 = fused epilogue; >1 = raw partial sums, reduced by splitk_reduce_kernel
   long long slab;     // elements per split-K slab
+  // fast kernel only
+  int kt_, kh_, kw_;  // kernel extents (tap decode)
+  int pad_off;        // pt*HW + ph*W + pw: makes every per-lane window origin offset non-negative
+  unsigned x_bytes;   // buffer range of x (plus pad_off*4)
 };
 
 template <int VW>
@@ -80,136 +84,17 @@ struct IgemmCfg {
   static constexpr int SMEM_FLOATS = AB_FLOATS > ST_FLOATS ? AB_FLOATS : ST_FLOATS;
 };
 
+// ---- epilogue shared by both implicit-GEMM kernels -------------------------------------------
+// accumulator element acc[jm][jn][r] of lane (li, lg):
+//   m = m0 + wm*WM + FM*(4*lg + r) + jm,   n = n0 + wn*WN + FN*li + jn
 template <int BM, int BN, int BK>
-__global__ __launch_bounds__(256) void conv3d_igemm_f32_kernel(const ConvArgs a) {
+__device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[BM / 32][BN / 32], float* smem, int split,
+                                               int m0, int n0, int wave, int lane) {
   using Cfg = IgemmCfg<BM, BN, BK>;
-  constexpr int FM = Cfg::FM, FN = Cfg::FN, KR = Cfg::KR, RA = Cfg::RA, RB = Cfg::RB;
-  static_assert(FM == 4 || FM == 2, "wave M tile must be 64 or 32");
-  static_assert(FN == 4 || FN == 2, "wave N tile must be 64 or 32");
-  static_assert(RA >= 1 && RB >= 1, "tile too small for 256 threads");
-
-  __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM_FLOATS];
-  float(*As)[BK][BM] = reinterpret_cast<float(*)[BK][BM]>(smem);
-  float(*Bs)[BK][BN] = reinterpret_cast<float(*)[BK][BN]>(smem + 2 * BK * BM);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ntiles = a.tiles_m * a.tiles_n;
-  int L, split;
-  if (a.splits > 1) {
-    // blocks b and b+8 share an XCD: keep one K-slice of the weights per XCD's L2
-    split = blockIdx.x % a.splits;
-    L = blockIdx.x / a.splits;
-  } else {
-    split = 0;
-    L = xcd_remap(blockIdx.x, ntiles);
-  }
-  const int tile_n = L % a.tiles_n, tile_m = L / a.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  // ---- gather coordinates of this thread's A column (one m, RA different k per tile) ----------
-  const int ml = tid % BM;
-  const int kr = __builtin_amdgcn_readfirstlane(tid / BM);  // wave-uniform (BM >= 64)
-  const int m = m0 + ml;
-  const bool mv = m < a.M;
-  int b = 0, ot = 0, oh = 0, ow = 0;
-  if (mv) {
-    b = m / a.THWo;
-    const int p = m - b * a.THWo;
-    ot = p / a.HWo;
-    const int q = p - ot * a.HWo;
-    oh = q / a.Wo;
-    ow = q - oh * a.Wo;
-  }
-  const int it0 = ot * a.st - a.pt, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
-  const unsigned Tlim = mv ? (unsigned)a.T : 0u;  // m out of range -> every tap invalid
-  const int mbase = b * a.Cin * a.THW + it0 * a.HW + ih0 * a.W + iw0;
-
-  float ra[RA];
-  float rb[RB][4];
-
-  auto load_tiles = [&](int k0) {
-#pragma unroll
-    for (int j = 0; j < RA; ++j) {
-      const int4 e = a.ktab[k0 + kr + KR * j];
-      const bool v = (unsigned)(it0 + e.y) < Tlim && (unsigned)(ih0 + e.z) < (unsigned)a.H &&
-                     (unsigned)(iw0 + e.w) < (unsigned)a.W;
-      ra[j] = v ? a.x[mbase + e.x] : 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < RB; ++j) {
-      const int idx = tid + 256 * j;
-      const int row = idx / (BN / 4), c4 = idx % (BN / 4);
-      const float4 t = *reinterpret_cast<const float4*>(a.w + (size_t)(k0 + row) * a.Cout + n0 + c4 * 4);
-      rb[j][0] = t.x; rb[j][1] = t.y; rb[j][2] = t.z; rb[j][3] = t.w;
-    }
-  };
-  auto store_tiles = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < RA; ++j) As[buf][kr + KR * j][ml] = ra[j];
-#pragma unroll
-    for (int j = 0; j < RB; ++j) {
-      const int idx = tid + 256 * j;
-      const int row = idx / (BN / 4), c4 = idx % (BN / 4);
-      *reinterpret_cast<float4*>(&Bs[buf][row][c4 * 4]) = make_float4(rb[j][0], rb[j][1], rb[j][2], rb[j][3]);
-    }
-  };
-
-  // ---- MFMA main loop ---------------------------------------------------------------------
-  const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves
+  constexpr int FM = Cfg::FM, FN = Cfg::FN;
+  const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lg = lane >> 4;
-  const int a_col = wm * Cfg::WM + FM * li;
   const int b_col = wn * Cfg::WN + FN * li;
-
-  f32x4 acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // k-tiles of this split: [kt0, kt1)
-  const int nk_all = a.Kpad / BK;
-  const int kt0 = (int)((long long)nk_all * split / a.splits);
-  const int kt1 = (int)((long long)nk_all * (split + 1) / a.splits);
-  if (kt0 < kt1) {
-    load_tiles(kt0 * BK);
-    store_tiles(0);
-  }
-  __syncthreads();
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int cur = (kt - kt0) & 1;
-    if (kt + 1 < kt1) load_tiles((kt + 1) * BK);
-#pragma unroll
-    for (int ks = 0; ks < BK / 4; ++ks) {
-      float av[FM], bv[FN];
-      if constexpr (FM == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(&As[cur][4 * ks + lg][a_col]);
-        av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
-      } else {
-        const float2 t = *reinterpret_cast<const float2*>(&As[cur][4 * ks + lg][a_col]);
-        av[0] = t.x; av[1] = t.y;
-      }
-      if constexpr (FN == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(&Bs[cur][4 * ks + lg][b_col]);
-        bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
-      } else {
-        const float2 t = *reinterpret_cast<const float2*>(&Bs[cur][4 * ks + lg][b_col]);
-        bv[0] = t.x; bv[1] = t.y;
-      }
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < kt1) store_tiles(cur ^ 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue ---------------------------------------------------------------------------
-  // accumulator element acc[jm][jn][r] of lane (li, lg):
-  //   m = m0 + wm*WM + FM*(4*lg + r) + jm,   n = n0 + wn*WN + FN*li + jn
   const bool fused = a.splits == 1;
   float* __restrict__ yout = a.y + (size_t)split * a.slab;
   if (a.vw == 4) {
@@ -316,6 +201,283 @@ __global__ __launch_bounds__(256) void conv3d_igemm_f32_kernel(const ConvArgs a)
   else emit(std::integral_constant<int, 1>{});
 }
 
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void conv3d_igemm_f32_kernel(const ConvArgs a) {
+  using Cfg = IgemmCfg<BM, BN, BK>;
+  constexpr int FM = Cfg::FM, FN = Cfg::FN, KR = Cfg::KR, RA = Cfg::RA, RB = Cfg::RB;
+  static_assert(FM == 4 || FM == 2, "wave M tile must be 64 or 32");
+  static_assert(FN == 4 || FN == 2, "wave N tile must be 64 or 32");
+  static_assert(RA >= 1 && RB >= 1, "tile too small for 256 threads");
+
+  __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM_FLOATS];
+  float(*As)[BK][BM] = reinterpret_cast<float(*)[BK][BM]>(smem);
+  float(*Bs)[BK][BN] = reinterpret_cast<float(*)[BK][BN]>(smem + 2 * BK * BM);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = a.tiles_m * a.tiles_n;
+  int L, split;
+  if (a.splits > 1) {
+    // blocks b and b+8 share an XCD: keep one K-slice of the weights per XCD's L2
+    split = blockIdx.x % a.splits;
+    L = blockIdx.x / a.splits;
+  } else {
+    split = 0;
+    L = xcd_remap(blockIdx.x, ntiles);
+  }
+  const int tile_n = L % a.tiles_n, tile_m = L / a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- gather coordinates of this thread's A column (one m, RA different k per tile) ----------
+  const int ml = tid % BM;
+  const int kr = __builtin_amdgcn_readfirstlane(tid / BM);  // wave-uniform (BM >= 64)
+  const int m = m0 + ml;
+  const bool mv = m < a.M;
+  int b = 0, ot = 0, oh = 0, ow = 0;
+  if (mv) {
+    b = m / a.THWo;
+    const int p = m - b * a.THWo;
+    ot = p / a.HWo;
+    const int q = p - ot * a.HWo;
+    oh = q / a.Wo;
+    ow = q - oh * a.Wo;
+  }
+  const int it0 = ot * a.st - a.pt, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
+  const unsigned Tlim = mv ? (unsigned)a.T : 0u;  // m out of range -> every tap invalid
+  const int mbase = b * a.Cin * a.THW + it0 * a.HW + ih0 * a.W + iw0;
+
+  float ra[RA];
+  float rb[RB][4];
+
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+      const int4 e = a.ktab[k0 + kr + KR * j];
+      const bool v = (unsigned)(it0 + e.y) < Tlim && (unsigned)(ih0 + e.z) < (unsigned)a.H &&
+                     (unsigned)(iw0 + e.w) < (unsigned)a.W;
+      ra[j] = v ? a.x[mbase + e.x] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int idx = tid + 256 * j;
+      const int row = idx / (BN / 4), c4 = idx % (BN / 4);
+      const float4 t = *reinterpret_cast<const float4*>(a.w + (size_t)(k0 + row) * a.Cout + n0 + c4 * 4);
+      rb[j][0] = t.x; rb[j][1] = t.y; rb[j][2] = t.z; rb[j][3] = t.w;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < RA; ++j) As[buf][kr + KR * j][ml] = ra[j];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int idx = tid + 256 * j;
+      const int row = idx / (BN / 4), c4 = idx % (BN / 4);
+      *reinterpret_cast<float4*>(&Bs[buf][row][c4 * 4]) = make_float4(rb[j][0], rb[j][1], rb[j][2], rb[j][3]);
+    }
+  };
+
+  // ---- MFMA main loop ---------------------------------------------------------------------
+  const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves
+  const int li = lane & 15, lg = lane >> 4;
+  const int a_col = wm * Cfg::WM + FM * li;
+  const int b_col = wn * Cfg::WN + FN * li;
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // k-tiles of this split: [kt0, kt1)
+  const int nk_all = a.Kpad / BK;
+  const int kt0 = (nk_all * split) / a.splits;
+  const int kt1 = (nk_all * (split + 1)) / a.splits;
+  if (kt0 < kt1) {
+    load_tiles(kt0 * BK);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    if (kt + 1 < kt1) load_tiles((kt + 1) * BK);
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      float av[FM], bv[FN];
+      if constexpr (FM == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(&As[cur][4 * ks + lg][a_col]);
+        av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
+      } else {
+        const float2 t = *reinterpret_cast<const float2*>(&As[cur][4 * ks + lg][a_col]);
+        av[0] = t.x; av[1] = t.y;
+      }
+      if constexpr (FN == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(&Bs[cur][4 * ks + lg][b_col]);
+        bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
+      } else {
+        const float2 t = *reinterpret_cast<const float2*>(&Bs[cur][4 * ks + lg][b_col]);
+        bv[0] = t.x; bv[1] = t.y;
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < kt1) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  igemm_epilogue<BM, BN, BK>(a, acc, smem, split, m0, n0, wave, lane);
+}
+
+// ================================================================================================
+// Fast-path implicit GEMM: same tiling / MFMA loop / epilogue as conv3d_igemm_f32_kernel, with the
+// per-element gather arithmetic hoisted out of the vector pipe.  The generic kernel spends ~14 VALU
+// instructions per gathered element (three range checks + 64-bit address), i.e. ~4.3 VALU per MFMA
+// on 64-wide N tiles (rocprofv3 PMC, profiles/r01_pmc_notes.md) -- more than an fp32 MFMA can
+// shadow.  Here every A element is one raw buffer load whose
+//   * per-lane voffset  = this thread's window origin (constant for the whole K loop),
+//   * scalar  soffset   = tap offset of row k from the gather table (SMEM/SALU),
+//   * validity          = one bit test of a per-thread tap mask built once per block (CHECK),
+//                         realised as an out-of-range voffset -> the buffer unit returns 0;
+//                         convs whose every tap is in range for every m (1x1x1, no padding) skip
+//                         even that (CHECK = false): 0 VALU per element.
+// Requires: taps <= 32 when CHECK, x and packed weights each < 3.75 GiB (32-bit buffer offsets).
+template <int BM, int BN, int BK, bool CHECK>
+__global__ __launch_bounds__(256) void conv3d_igemm_fast_kernel(const ConvArgs a) {
+  using Cfg = IgemmCfg<BM, BN, BK>;
+  constexpr int FM = Cfg::FM, FN = Cfg::FN, KR = Cfg::KR, RA = Cfg::RA, RB = Cfg::RB;
+  constexpr unsigned OOB = 0xFFFFFF00u;
+
+  __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM_FLOATS];
+  float(*As)[BK][BM] = reinterpret_cast<float(*)[BK][BM]>(smem);
+  float(*Bs)[BK][BN] = reinterpret_cast<float(*)[BK][BN]>(smem + 2 * BK * BM);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = a.tiles_m * a.tiles_n;
+  int L, split;
+  if (a.splits > 1) {
+    split = blockIdx.x % a.splits;
+    L = blockIdx.x / a.splits;
+  } else {
+    split = 0;
+    L = xcd_remap(blockIdx.x, ntiles);
+  }
+  const int tile_n = L % a.tiles_n, tile_m = L / a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- this thread's A column: window origin (voffset) and tap-validity mask ------------------
+  const int ml = tid % BM;
+  const int kr = __builtin_amdgcn_readfirstlane(tid / BM);
+  const int m = m0 + ml;
+  unsigned vbase = OOB;
+  unsigned vmask = 0;
+  if (m < a.M) {
+    const int b = m / a.THWo;
+    const int p = m - b * a.THWo;
+    const int ot = p / a.HWo;
+    const int q = p - ot * a.HWo;
+    const int oh = q / a.Wo;
+    const int ow = q - oh * a.Wo;
+    const int it0 = ot * a.st - a.pt, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
+    vbase = (unsigned)(b * a.Cin * a.THW + it0 * a.HW + ih0 * a.W + iw0 + a.pad_off) * 4u;
+    if constexpr (CHECK) {
+      int tap = 0;
+      for (int dt = 0; dt < a.kt_; ++dt)
+        for (int dh = 0; dh < a.kh_; ++dh)
+          for (int dw = 0; dw < a.kw_; ++dw, ++tap) {
+            const bool v = (unsigned)(it0 + dt) < (unsigned)a.T && (unsigned)(ih0 + dh) < (unsigned)a.H &&
+                           (unsigned)(iw0 + dw) < (unsigned)a.W;
+            vmask |= (v ? 1u : 0u) << tap;
+          }
+    }
+  }
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) - a.pad_off, 0, a.x_bytes, 0x00020000);
+
+  const int2* __restrict__ ktab2 = reinterpret_cast<const int2*>(a.ktab + a.Kpad);
+  float ra[RA];
+  float rb[RB][4];
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+      const int2 e = ktab2[k0 + kr + KR * j];  // wave-uniform -> scalar loads; {byte offset, tap bit}
+      unsigned voff = vbase;
+      if constexpr (CHECK) voff = (vmask & (unsigned)e.y) ? vbase : OOB;
+      ra[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff, e.x, 0));
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int idx = tid + 256 * j;
+      const int row = idx / (BN / 4), c4 = idx % (BN / 4);
+      const float4 t = *reinterpret_cast<const float4*>(a.w + (size_t)(k0 + row) * a.Cout + n0 + c4 * 4);
+      rb[j][0] = t.x; rb[j][1] = t.y; rb[j][2] = t.z; rb[j][3] = t.w;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < RA; ++j) As[buf][kr + KR * j][ml] = ra[j];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int idx = tid + 256 * j;
+      const int row = idx / (BN / 4), c4 = idx % (BN / 4);
+      *reinterpret_cast<float4*>(&Bs[buf][row][c4 * 4]) = make_float4(rb[j][0], rb[j][1], rb[j][2], rb[j][3]);
+    }
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lg = lane >> 4;
+  const int a_col = wm * Cfg::WM + FM * li;
+  const int b_col = wn * Cfg::WN + FN * li;
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk_all = a.Kpad / BK;
+  const int kt0 = (nk_all * split) / a.splits;
+  const int kt1 = (nk_all * (split + 1)) / a.splits;
+  if (kt0 < kt1) {
+    load_tiles(kt0 * BK);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    if (kt + 1 < kt1) load_tiles((kt + 1) * BK);
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      float av[FM], bv[FN];
+      if constexpr (FM == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(&As[cur][4 * ks + lg][a_col]);
+        av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
+      } else {
+        const float2 t = *reinterpret_cast<const float2*>(&As[cur][4 * ks + lg][a_col]);
+        av[0] = t.x; av[1] = t.y;
+      }
+      if constexpr (FN == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(&Bs[cur][4 * ks + lg][b_col]);
+        bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
+      } else {
+        const float2 t = *reinterpret_cast<const float2*>(&Bs[cur][4 * ks + lg][b_col]);
+        bv[0] = t.x; bv[1] = t.y;
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < kt1) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+  igemm_epilogue<BM, BN, BK>(a, acc, smem, split, m0, n0, wave, lane);
+}
+
 // y = act(sum_s slab[s] * scale[c] + shift[c] (+ res)), slabs in NCDHW like y
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ scale,
                                      const float* __restrict__ shift, const float* __restrict__ res,
@@ -378,6 +540,16 @@ __global__ void build_ktab_kernel(int4* __restrict__ ktab, int kt, int kh, int k
       e = make_int4(0, 1 << 28, 0, 0);  // fails the temporal range check: contributes exact zeros
     }
     ktab[k] = e;
+    // second table for the fast kernel: {byte offset, tap bit (0 for padding rows)}
+    int2* t2 = reinterpret_cast<int2*>(ktab + Kpad);
+    int2 f;
+    if (k < K) {
+      const int tap = k % taps;
+      f = make_int2(e.x * 4, taps <= 32 ? (int)(1u << tap) : 0);
+    } else {
+      f = make_int2(0, 0);
+    }
+    t2[k] = f;
   }
 }
 
@@ -463,10 +635,17 @@ struct Choice {
 };
 
 static void tile_of(int algo, int* BM, int* BN, int* BK) {
+  if (algo >= ADVHIP_ALGO_FAST_BASE) algo -= ADVHIP_ALGO_FAST_BASE;
   const int t = (algo - 1) & 3;
   *BM = (t == 0 || t == 1) ? 128 : 64;
   *BN = (t == 0 || t == 3) ? 128 : 64;
   *BK = algo >= ADVHIP_ALGO_IGEMM_128x128x32 ? 32 : 16;
+}
+
+// the fast kernel covers convs with <= 32 taps on tensors addressable by 32-bit byte offsets
+static bool fast_ok(const advhip_conv3d_desc* d, long long in_elems, long long w_elems) {
+  const long long pad_off = (long long)d->pt * d->H * d->W + (long long)d->ph * d->W + d->pw;
+  return d->kt * d->kh * d->kw <= 32 && (in_elems + pad_off) * 4 < 0xF0000000ll && w_elems * 4 < 0xF0000000ll;
 }
 
 // Heuristic used when the caller does not pin algo/splits (the Python engine normally pins both
@@ -482,7 +661,9 @@ static Choice choose(const advhip_conv3d_desc* d, long long M, int Kpad) {
     else if (t128 * (N / 64) >= 1024) c.algo = ADVHIP_ALGO_IGEMM_128x64;
     else if (n128 && t64 * (N / 128) >= 768) c.algo = ADVHIP_ALGO_IGEMM_64x128;
     else if (t64 * (N / 64) >= 768) c.algo = ADVHIP_ALGO_IGEMM_64x64;
-    else c.algo = n128 ? ADVHIP_ALGO_IGEMM_128x128x32 : ADVHIP_ALGO_IGEMM_128x64x32;  // + split-K below
+    else c.algo = n128 ? ADVHIP_ALGO_IGEMM_64x128 : ADVHIP_ALGO_IGEMM_64x64;  // + split-K below
+    const long long in_elems = (long long)d->B * d->Cin * d->T * d->H * d->W;
+    if (fast_ok(d, in_elems, (long long)Kpad * N)) c.algo += ADVHIP_ALGO_FAST_BASE;
   }
   if (c.splits <= 0) {
     int BM, BN, BK;
@@ -554,7 +735,16 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
   const Choice c = choose(d, M, g.Kpad);
   int BM, BN, BK;
   tile_of(c.algo, &BM, &BN, &BK);
-  ADVHIP_REQUIRE(c.algo >= ADVHIP_ALGO_IGEMM_128x128 && c.algo <= ADVHIP_ALGO_IGEMM_64x128x32, "conv3d: unknown algo %d", c.algo);
+  const bool fast = c.algo >= ADVHIP_ALGO_FAST_BASE;
+  const int base_algo = fast ? c.algo - ADVHIP_ALGO_FAST_BASE : c.algo;
+  ADVHIP_REQUIRE(base_algo >= ADVHIP_ALGO_IGEMM_128x128 && base_algo <= ADVHIP_ALGO_IGEMM_64x128x32, "conv3d: unknown algo %d", c.algo);
+  if (fast) {
+    ADVHIP_REQUIRE(fast_ok(d, in_elems, (long long)g.Kpad * d->Cout),
+                   "conv3d: fast kernel needs <= 32 taps and < 3.75 GiB operands (taps=%d)", d->kt * d->kh * d->kw);
+    a.kt_ = d->kt; a.kh_ = d->kh; a.kw_ = d->kw;
+    a.pad_off = d->pt * d->H * d->W + d->ph * d->W + d->pw;
+    a.x_bytes = (unsigned)((in_elems + a.pad_off) * 4);
+  }
   ADVHIP_REQUIRE(d->Cout % BN == 0, "conv3d: Cout=%d not a multiple of the %d-wide N tile", d->Cout, BN);
   ADVHIP_REQUIRE(g.Kpad % BK == 0 || BK == 16, "conv3d: internal: Kpad");
   a.splits = c.splits;
@@ -575,7 +765,22 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
   // BK = 32 needs Kpad % 32 == 0: the packed weights are padded to 16 rows only, but the k-table
   // marks rows >= K invalid and the weight rows read beyond Kpad must exist -> require it.
   if (BK == 32) ADVHIP_REQUIRE(g.Kpad % 32 == 0, "conv3d: BK=32 variants need K padded to 32 (K=%d)", g.K);
+  // every tap of every output position inside the input: no validity mask needed
+  const bool nocheck = d->kt == 1 && d->kh == 1 && d->kw == 1 && d->pt == 0 && d->ph == 0 && d->pw == 0 && g.K == g.Kpad;
+#define ADVHIP_FAST_CASE(ID, BM_, BN_, BK_)                                                                         \
+  case ADVHIP_ALGO_FAST_BASE + ID:                                                                                  \
+    if (nocheck) hipLaunchKernelGGL((conv3d_igemm_fast_kernel<BM_, BN_, BK_, false>), grid, dim3(256), 0, st, a);   \
+    else hipLaunchKernelGGL((conv3d_igemm_fast_kernel<BM_, BN_, BK_, true>), grid, dim3(256), 0, st, a);            \
+    break;
   switch (c.algo) {
+    ADVHIP_FAST_CASE(ADVHIP_ALGO_IGEMM_128x128, 128, 128, 16)
+    ADVHIP_FAST_CASE(ADVHIP_ALGO_IGEMM_128x64, 128, 64, 16)
+    ADVHIP_FAST_CASE(ADVHIP_ALGO_IGEMM_64x64, 64, 64, 16)
+    ADVHIP_FAST_CASE(ADVHIP_ALGO_IGEMM_64x128, 64, 128, 16)
+    ADVHIP_FAST_CASE(ADVHIP_ALGO_IGEMM_128x128x32, 128, 128, 32)
+    ADVHIP_FAST_CASE(ADVHIP_ALGO_IGEMM_128x64x32, 128, 64, 32)
+    ADVHIP_FAST_CASE(ADVHIP_ALGO_IGEMM_64x64x32, 64, 64, 32)
+    ADVHIP_FAST_CASE(ADVHIP_ALGO_IGEMM_64x128x32, 64, 128, 32)
     case ADVHIP_ALGO_IGEMM_128x128: hipLaunchKernelGGL((conv3d_igemm_f32_kernel<128, 128, 16>), grid, dim3(256), 0, st, a); break;
     case ADVHIP_ALGO_IGEMM_128x64: hipLaunchKernelGGL((conv3d_igemm_f32_kernel<128, 64, 16>), grid, dim3(256), 0, st, a); break;
     case ADVHIP_ALGO_IGEMM_64x64: hipLaunchKernelGGL((conv3d_igemm_f32_kernel<64, 64, 16>), grid, dim3(256), 0, st, a); break;

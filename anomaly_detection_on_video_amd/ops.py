@@ -85,7 +85,7 @@ def _packed_rows(d: ConvDesc) -> int:
 
 def _build_ktab(pc: PackedConv, thw: Tuple[int, int, int]) -> torch.Tensor:
     d = pc.desc(1, *thw, relu=False)
-    ktab = torch.empty((_packed_rows(d), 4), device=pc.w_packed.device, dtype=torch.int32)
+    ktab = torch.empty((_packed_rows(d) * 6,), device=pc.w_packed.device, dtype=torch.int32)
     check(_lib.load().advhip_conv3d_build_ktab(C.byref(d), ptr(ktab), stream()), "build_ktab")
     return ktab
 

@@ -42,6 +42,8 @@ extern "C" {
 #define ADVHIP_ALGO_IGEMM_128x64x32 6
 #define ADVHIP_ALGO_IGEMM_64x64x32 7
 #define ADVHIP_ALGO_IGEMM_64x128x32 8
+/* + tile id 1..8: same tiles, gather arithmetic hoisted to scalar offsets + tap bit-mask (<= 32 taps) */
+#define ADVHIP_ALGO_FAST_BASE 32
 #define ADVHIP_ALGO_STEM 16 /* dedicated Cin=3 k(5,7,7) s2 kernel, LDS halo tile */
 
 typedef struct advhip_conv3d_desc {
@@ -75,7 +77,8 @@ int advhip_conv3d_pack_weight_f32(const advhip_conv3d_desc* d, const float* w, f
 
 /* Per-row gather table for one input size (d->T, d->H, d->W):
  * ktab[k] = {input element offset of tap k relative to the window origin, dt, dh, dw}; rows
- * above K are marked out-of-range so they contribute exact zeros.  int32[Kpad][4]. */
+ * above K are marked out-of-range so they contribute exact zeros, followed by the fast kernels'
+ * compact table {byte offset, tap bit}.  int32[Kpad][4] + int32[Kpad][2] = 6*Kpad int32. */
 int advhip_conv3d_build_ktab(const advhip_conv3d_desc* d, int32_t* ktab, void* stream);
 
 /* Fold eval-mode BatchNorm into per-channel scale/shift:

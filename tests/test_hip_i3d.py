@@ -77,15 +77,26 @@ def _conv_case(name, cin, cout, k, s, p, bthw):
     return x, wt, g, be, mu, var, res
 
 
+ALGOS = [0] + list(range(1, 9)) + list(range(33, 41))
+TILE_IDS = ["128x128", "128x64", "64x64", "64x128", "128x128x32", "128x64x32", "64x64x32", "64x128x32"]
+
+
+def _skip_algo(algo, cout, k):
+    base = algo - 32 if algo >= 32 else algo
+    if base in (1, 4, 5, 8) and cout % 128:
+        pytest.skip("Cout not a multiple of the 128-wide N tile")
+    if algo >= 32 and k[0] * k[1] * k[2] > 32:
+        pytest.skip("fast kernel covers <= 32 taps")
+
+
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4, 5, 6, 7, 8], ids=["auto", "128x128", "128x64", "64x64", "64x128", "128x128x32", "128x64x32", "64x64x32", "64x128x32"])
+@pytest.mark.parametrize("algo", ALGOS, ids=["auto"] + TILE_IDS + ["fast" + t for t in TILE_IDS])
 def test_conv_bn_act_vs_oracle(case, algo):
     from anomaly_detection_on_video_amd import ops
     from oracle import i3d_oracle
 
     name, cin, cout, k, s, p, bthw = case
-    if algo in (1, 4, 5, 8) and cout % 128:
-        pytest.skip("Cout not a multiple of the 128-wide N tile")
+    _skip_algo(algo, cout, k)
     x, wt, g, be, mu, var, res = _conv_case(*case)
     dev = _dev()
     pc = ops.pack_conv(wt.to(dev), g.to(dev), be.to(dev), mu.to(dev), var.to(dev), 1e-5, s, p, name=name)
@@ -101,20 +112,19 @@ def test_conv_bn_act_vs_oracle(case, algo):
 
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0] in ("l2.conv2", "l3.conv1.t3", "l4.conv2", "edge.7x7", "l1.conv3", "edge.odd")],
                          ids=lambda c: c[0])
-@pytest.mark.parametrize("algo,splits", [(3, 2), (1, 3), (7, 4), (6, 2), (0, 0)])
+@pytest.mark.parametrize("algo,splits", [(3, 2), (1, 3), (7, 4), (6, 2), (0, 0), (35, 2), (36, 3), (39, 4)])
 def test_conv_split_k_vs_oracle(case, algo, splits):
     """split-K slabs + fixed-order reduce pass: same parity bar, and bit-identical run to run."""
     from anomaly_detection_on_video_amd import ops
     from oracle import i3d_oracle
 
     name, cin, cout, k, s, p, bthw = case
-    if algo in (1, 4, 5, 8) and cout % 128:
-        pytest.skip("Cout not a multiple of the 128-wide N tile")
+    _skip_algo(algo, cout, k)
     x, wt, g, be, mu, var, res = _conv_case(*case)
     dev = _dev()
     pc = ops.pack_conv(wt.to(dev), g.to(dev), be.to(dev), mu.to(dev), var.to(dev), 1e-5, s, p, name=name)
     kpad = pc.w_packed.shape[0]
-    bk = 32 if algo >= 5 else 16
+    bk = 32 if (algo % 32) >= 5 else 16
     if splits > kpad // bk:
         pytest.skip("fewer k-tiles than splits")
     ref = i3d_oracle.conv_bn_act(x, wt, g, be, mu, var, s, p, res, True)

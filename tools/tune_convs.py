@@ -66,7 +66,8 @@ def main():
         else:
             kpad = pc.w_packed.shape[0]
             cands = []
-            for algo in _lib.IGEMM_ALGOS:
+            taps = pc.kernel[0] * pc.kernel[1] * pc.kernel[2]
+            for algo in _lib.IGEMM_ALGOS + (_lib.FAST_ALGOS if taps <= 32 else ()):
                 bm, bn, bk = _lib.algo_tile(algo)
                 if pc.cout % bn:
                     continue
