@@ -40,6 +40,14 @@ class ExtractScoreStream:
         Returns (gathered features (global_batch, 2048), [(video index, scores (clips,)) ...])."""
         feats = self.backbone(local_clips).reshape(local_clips.shape[0], -1)
         gathered = adist.all_gather_rows(feats) if self.world > 1 else feats
+        return gathered, self.ingest(gathered)
+
+    @torch.no_grad()
+    def ingest(self, gathered: torch.Tensor) -> List[Tuple[int, torch.Tensor]]:
+        """Append one global batch of feature rows (stream order) to the ring and score every video
+        owned by this rank (video v -> rank v % world) whose last crop-clip just arrived."""
+        if gathered.shape[0] != self.global_batch:
+            raise ValueError(f"expected {self.global_batch} rows per global batch, got {gathered.shape[0]}")
         start = self.pos % self.ring_rows
         self.ring[start : start + self.global_batch].copy_(gathered)
         first_done = self.pos // self.per_video  # videos complete before this batch
@@ -51,7 +59,7 @@ class ExtractScoreStream:
             r0 = (v * self.per_video) % self.ring_rows
             vid = self.ring[r0 : r0 + self.per_video].view(self.clips_per_video, self.ncrops, -1)
             scored.append((v, self.score_video(vid)))
-        return gathered, scored
+        return scored
 
     @torch.no_grad()
     def score_video(self, feats: torch.Tensor) -> torch.Tensor:

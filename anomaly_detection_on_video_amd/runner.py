@@ -1,0 +1,225 @@
+"""Training / validation orchestration for the MIL scorer.
+
+`VideoAnomalyDetectionRunner` keeps the reference LightningModule's constructor and hook names
+(`/root/reference/src/runner.py:18-140`): training_step / validation_step / configure_optimizers /
+on_validation_epoch_end / setup / train_dataloader / val_dataloader.  Lightning, wandb and
+matplotlib are not in the target image, so the hooks are driven by the plain `Trainer` below
+(automatic optimisation: zero_grad -> training_step -> backward -> Adam step; validation every
+epoch; JSONL logging; last / top-k checkpoints), which the shipped `configs/trainer/default.yaml`
+instantiates instead of `lightning.pytorch.Trainer`.
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from . import metrics
+from .dataset import build_feature_dataset
+
+
+class VideoAnomalyDetectionRunner:
+    def __init__(self, model: torch.nn.Module, optimizer, data):
+        self.model = model
+        self.hparams = type("HParams", (), {"optimizer": optimizer, "data": data})()
+        self.validation_step_outputs: List[Dict[str, np.ndarray]] = []
+        self.logged: Dict[str, float] = {}
+        self.device = torch.device("cpu")
+
+    # -- logging hook the Trainer reads back
+    def log(self, name: str, value, **_kw) -> None:
+        self.logged[name] = float(value.detach()) if torch.is_tensor(value) else float(value)
+
+    def to(self, device):
+        self.device = torch.device(device)
+        self.model.to(self.device)
+        return self
+
+    # runner.py:29-39 -- normal batch first, abnormal second
+    def training_step(self, batch, batch_idx) -> torch.Tensor:
+        ninputs, ainputs = batch
+        inputs = torch.cat((ninputs["feature"], ainputs["feature"]), dim=0)
+        outputs = self.model(video=inputs, abnormal_labels=ainputs["anomaly"], normal_labels=ninputs["anomaly"])
+        self.log("train_loss", outputs.loss)
+        return outputs.loss
+
+    # runner.py:42-50 -- one video per step: (1, T, 10, 2049) -> (1, 10, T, 2049)
+    def validation_step(self, batch, batch_idx) -> None:
+        features = batch["feature"].permute(0, 2, 1, 3).contiguous()
+        outputs = self.model(video=features)
+        self.validation_step_outputs.append({
+            "preds": outputs.scores.squeeze(0).squeeze(-1).detach().cpu().numpy(),
+            "labels": batch["label"].squeeze(0).cpu().numpy(),
+        })
+
+    # runner.py:53-59 -- Adam with L2-in-gradient weight decay, no scheduler
+    def configure_optimizers(self) -> List[torch.optim.Optimizer]:
+        opt = self.hparams.optimizer
+        return [torch.optim.Adam(self.model.parameters(), lr=float(opt["learning_rate"]), weight_decay=float(opt["weight_decay"]))]
+
+    # runner.py:62-90 (metrics; the matplotlib/wandb chart is out of scope)
+    def on_validation_epoch_end(self) -> Dict[str, float]:
+        outs = self.validation_step_outputs
+        rec_auc, pr_auc = metrics.frame_level_auc([o["preds"] for o in outs], [o["labels"] for o in outs],
+                                                  int(self.hparams.data["frames_per_clip"]))
+        self.log("valid/rec_auc", rec_auc)
+        self.log("valid/pr_auc", pr_auc)
+        self.validation_step_outputs = []
+        return {"valid/rec_auc": rec_auc, "valid/pr_auc": pr_auc}
+
+    # runner.py:93-105
+    def setup(self, stage: str = "fit") -> None:
+        d = self.hparams.data
+        kw = dict(revision=d.get("revision", "main"), cache_dir=d.get("cache_dir"), dynamic_load=bool(d.get("dynamic_load", False)))
+        local = d.get("local_path")
+        self.train_dataset = build_feature_dataset(mode="train", local_path=local, filename="train.zip" if local else None, **kw)
+        self.valid_dataset = build_feature_dataset(mode="test", local_path=local, filename="test.zip" if local else None, **kw)
+
+    # runner.py:108-124 -- two loaders zipped, shuffle=False, drop_last=True
+    def train_dataloader(self) -> Tuple[DataLoader, DataLoader]:
+        d = self.hparams.data
+        mk = lambda ds: DataLoader(ds, batch_size=int(d["batch_size"]), shuffle=False, drop_last=True, num_workers=int(d.get("num_workers", 0)))
+        return mk(self.train_dataset["normal"]), mk(self.train_dataset["abnormal"])
+
+    def val_dataloader(self) -> DataLoader:
+        return DataLoader(self.valid_dataset, batch_size=1, shuffle=False)
+
+    def on_load_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
+        pass
+
+    def on_save_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
+        pass
+
+
+def _to_device(batch, device):
+    if torch.is_tensor(batch):
+        return batch.to(device=device, dtype=torch.float32 if batch.is_floating_point() else None, non_blocking=True)
+    if isinstance(batch, dict):
+        return {k: _to_device(v, device) for k, v in batch.items()}
+    if isinstance(batch, (tuple, list)):
+        return type(batch)(_to_device(v, device) for v in batch)
+    return batch
+
+
+class JSONLLogger:
+    """Append one JSON object per log call (stands in for the wandb logger)."""
+
+    def __init__(self, path: str = "logs/train.jsonl", **_ignored):
+        self.path = path
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+
+    def log_metrics(self, m: Dict[str, float], step: int) -> None:
+        with open(self.path, "a") as f:
+            f.write(json.dumps({"step": step, "time": time.time(), **m}) + "\n")
+
+
+class LearningRateMonitor:
+    def __init__(self, logging_interval: str = "step"):
+        self.logging_interval = logging_interval
+
+    def on_step(self, trainer, optimizer) -> Dict[str, float]:
+        return {"lr-Adam": optimizer.param_groups[0]["lr"]}
+
+
+class ModelCheckpoint:
+    """dirpath/last.pt every `every_n_epochs` epochs (+ top-k by `monitor`).  The reference's config
+    monitors `rec_auc` while the runner logs `valid/rec_auc`: both spellings work."""
+
+    def __init__(self, dirpath: str = "checkpoints", save_last: bool = True, save_top_k: int = 10, every_n_epochs: int = 10,
+                 monitor: str = "rec_auc", mode: str = "max", verbose: bool = False):
+        self.dirpath, self.save_last, self.save_top_k = dirpath, save_last, save_top_k
+        self.every_n_epochs, self.monitor, self.mode, self.verbose = every_n_epochs, monitor, mode, verbose
+        self.best: List[Tuple[float, str]] = []
+
+    def on_epoch_end(self, trainer, runner, optimizer, epoch: int, metrics_: Dict[str, float]) -> None:
+        if (epoch + 1) % max(1, self.every_n_epochs):
+            return
+        os.makedirs(self.dirpath, exist_ok=True)
+        state = {"model": runner.model.state_dict(), "optimizer": optimizer.state_dict(), "epoch": epoch, "metrics": metrics_}
+        runner.on_save_checkpoint(state)
+        if self.save_last:
+            torch.save(state, os.path.join(self.dirpath, "last.pt"))
+        val = metrics_.get(self.monitor, metrics_.get("valid/" + self.monitor))
+        if val is None or self.save_top_k == 0:
+            return
+        path = os.path.join(self.dirpath, f"epoch={epoch}-{self.monitor.replace('/', '_')}={val:.4f}.pt")
+        torch.save(state, path)
+        self.best.append((val if self.mode == "max" else -val, path))
+        self.best.sort(reverse=True)
+        for _, stale in self.best[self.save_top_k :]:
+            if os.path.exists(stale):
+                os.remove(stale)
+        self.best = self.best[: self.save_top_k]
+
+
+class Trainer:
+    """Plain single-device fit loop with Lightning's keyword names (configs/trainer/default.yaml)."""
+
+    def __init__(self, accelerator: str = "auto", gradient_clip_val: Optional[float] = None, max_steps: int = -1,
+                 max_epochs: int = 1000, log_every_n_steps: Optional[int] = None, precision: str = "32-true",
+                 logger=None, callbacks=None, check_val_every_n_epoch: int = 1, **_ignored):
+        if str(precision) not in ("32-true", "32"):
+            raise ValueError("the MI355X path computes in fp32 (precision: 32-true)")
+        self.gradient_clip_val, self.max_steps, self.max_epochs = gradient_clip_val, max_steps, max_epochs
+        self.log_every_n_steps = log_every_n_steps or 1
+        self.loggers = list(logger or [])
+        self.callbacks = list(callbacks or [])
+        self.check_val_every_n_epoch = check_val_every_n_epoch
+        if accelerator not in ("auto", "gpu", "cuda"):
+            raise ValueError(f"accelerator={accelerator!r}: the scorer's MIL head and losses are HIP kernels (GPU only)")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no AMD GPU visible: Trainer.fit needs one (there is no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.global_step = 0
+        self.history: List[Dict[str, float]] = []
+
+    def _log(self, m: Dict[str, float]) -> None:
+        self.history.append({"step": self.global_step, **m})
+        for lg in self.loggers:
+            lg.log_metrics(m, self.global_step)
+
+    def fit(self, model: VideoAnomalyDetectionRunner) -> None:
+        runner = model.to(self.device)
+        runner.setup("fit")
+        (optimizer,) = runner.configure_optimizers()
+        for epoch in range(self.max_epochs):
+            runner.model.train()
+            nloader, aloader = runner.train_dataloader()
+            for batch_idx, batch in enumerate(zip(nloader, aloader)):
+                if 0 <= self.max_steps <= self.global_step:
+                    break
+                batch = _to_device(batch, self.device)
+                optimizer.zero_grad(set_to_none=True)
+                loss = runner.training_step(batch, batch_idx)
+                loss.backward()
+                if self.gradient_clip_val:
+                    torch.nn.utils.clip_grad_norm_(runner.model.parameters(), self.gradient_clip_val)
+                optimizer.step()
+                self.global_step += 1
+                if self.global_step % self.log_every_n_steps == 0:
+                    m = {"train_loss": runner.logged["train_loss"], "epoch": epoch}
+                    for cb in self.callbacks:
+                        if hasattr(cb, "on_step"):
+                            m.update(cb.on_step(self, optimizer))
+                    self._log(m)
+            epoch_metrics: Dict[str, float] = {}
+            if (epoch + 1) % self.check_val_every_n_epoch == 0:
+                epoch_metrics = self.validate(runner)
+                self._log({**epoch_metrics, "epoch": epoch})
+            for cb in self.callbacks:
+                if hasattr(cb, "on_epoch_end"):
+                    cb.on_epoch_end(self, runner, optimizer, epoch, epoch_metrics)
+            if 0 <= self.max_steps <= self.global_step:
+                break
+
+    @torch.no_grad()
+    def validate(self, runner: VideoAnomalyDetectionRunner) -> Dict[str, float]:
+        runner.model.eval()
+        for i, batch in enumerate(runner.val_dataloader()):
+            runner.validation_step(_to_device(batch, self.device), i)
+        return runner.on_validation_epoch_end()

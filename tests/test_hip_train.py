@@ -1,0 +1,157 @@
+"""GPU tests of the callers either side of the kernels: MIL training steps (BASELINE config 4),
+the run.py entry point on a synthetic corpus, and the extraction driver (extract -> segment)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, rel_err
+from anomaly_detection_on_video_amd.weights import synth_i3d_state_dict, synth_module_state_dict, synth_tensor
+from test_oracle_golden import mgfn_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-3
+
+
+def test_adam_training_steps_track_the_cpu_oracle():
+    """3 Adam steps (lr 1e-3, weight decay 5e-4: runner.py:53-59) in train mode (BatchNorm1d batch
+    statistics) with the top-k keep-mask pinned to ones: loss curve and weights vs the oracle."""
+    from anomaly_detection_on_video_amd.models.mgfn import MGFNConfig, MGFNForVideoAnomalyDetection
+    from oracle import mgfn_oracle
+
+    model = MGFNForVideoAnomalyDetection(MGFNConfig())
+    sd = synth_module_state_dict(model)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    ones = torch.ones(2, 32)
+    model.injected_keep = (ones.to(DEV), ones.to(DEV))
+    params = {k: v.clone().requires_grad_(v.is_floating_point() and "running_" not in k and "num_batches" not in k) for k, v in sd.items()}
+    learn = [k for k, v in params.items() if v.requires_grad]
+    assert learn == [n for n, _ in model.named_parameters()]
+    opt_g = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
+    opt_c = torch.optim.Adam([params[k] for k in learn], lr=1e-3, weight_decay=5e-4)
+    nl, al = torch.zeros(2), torch.ones(2)
+    losses_g, losses_c = [], []
+    for step in range(3):
+        video = mgfn_inputs(4, 32, 10 + step)
+        opt_g.zero_grad()
+        out = model(video=video.to(DEV), abnormal_labels=al.to(DEV), normal_labels=nl.to(DEV))
+        out.loss.backward()
+        opt_g.step()
+        losses_g.append(float(out.loss))
+        opt_c.zero_grad()
+        # the oracle's BatchNorm1d running stats are not carried over between steps (train mode
+        # normalises with batch statistics, so they do not influence the forward)
+        o = mgfn_oracle.mgfn_forward(video, params, abnormal_labels=al, normal_labels=nl, training=True, keep_abn=ones, keep_nor=ones)
+        o.loss.backward()
+        opt_c.step()
+        losses_c.append(float(o.loss))
+    assert rel_err(torch.tensor(losses_g), torch.tensor(losses_c)) < TOL, (losses_g, losses_c)
+    assert losses_g[0] != losses_g[1]
+    # Adam's first steps are sign-like (|update| ~ lr), so compare the parameter *change*
+    d_g = model.fc.weight.detach().cpu() - sd["fc.weight"]
+    d_c = params["fc.weight"].detach() - sd["fc.weight"]
+    assert rel_err(d_g, d_c) < 5e-2
+    assert rel_err(model.fc.weight.detach().cpu(), params["fc.weight"].detach()) < TOL
+
+
+def test_run_py_trains_on_synthetic_corpus(tmp_path):
+    from anomaly_detection_on_video_amd.dataset import write_synthetic_feature_zips
+    import run
+
+    data_dir = write_synthetic_feature_zips(str(tmp_path / "feat"), n_normal=4, n_abnormal=4, n_test=4, seed=1)
+    ckpt = str(tmp_path / "ckpt")
+    logp = str(tmp_path / "log.jsonl")
+    torch.manual_seed(0)
+    trainer = run.main([
+        "data=synthetic", f"data.local_path={data_dir}", "data.batch_size=2", "trainer.cls.max_epochs=2",
+        f"trainer.callbacks.model_checkpoint.dirpath={ckpt}", "trainer.callbacks.model_checkpoint.every_n_epochs=1",
+        f"trainer.logger.jsonl.path={logp}",
+    ])
+    steps = [h for h in trainer.history if "train_loss" in h]
+    vals = [h for h in trainer.history if "valid/rec_auc" in h]
+    assert len(steps) == 4 and len(vals) == 2  # 4 videos per class / batch 2 = 2 steps x 2 epochs
+    assert all(np.isfinite(h["train_loss"]) for h in steps)
+    assert all(0.0 <= h["valid/rec_auc"] <= 1.0 and 0.0 <= h["valid/pr_auc"] <= 1.0 for h in vals)
+    assert os.path.exists(os.path.join(ckpt, "last.pt"))
+    state = torch.load(os.path.join(ckpt, "last.pt"), map_location="cpu")
+    assert state["epoch"] == 1 and "fc.weight" in state["model"]
+    lines = [json.loads(l) for l in open(logp)]
+    assert any("lr-Adam" in l for l in lines) and any("valid/pr_auc" in l for l in lines)
+
+
+def test_extract_driver_layout_resume_and_segment(tmp_path):
+    """extract_video == per-crop oracle forwards stacked the reference's way; skip-if-exists resume;
+    segment() file driver == host oracle."""
+    from anomaly_detection_on_video_amd import extract
+    from anomaly_detection_on_video_amd.i3d import I3Res50
+    from oracle import host_oracle, i3d_oracle
+
+    sd = synth_i3d_state_dict()
+    model = I3Res50()
+    model.load_state_dict(sd)
+    model = model.eval().to(DEV)
+    # 3 clips x 10 crops of a small frame size keep the CPU oracle fast: (n, 10, T=16, 3, 64, 64)
+    clips = synth_tensor("extract.clips", (3, 10, 16, 3, 64, 64), scale=2.0)
+    feats = extract.extract_video(model, clips, batch_size=2, max_crop_clips=8)
+    assert feats.shape == (3, 10, 2048) and feats.dtype == np.float32
+    # reference layout: outputs[batch][crop] = model(inputs[:, crop]) (extract_features.py:83-100)
+    x = clips.permute(0, 1, 3, 2, 4, 5)
+    per_batch = []
+    for b0 in (0, 2):
+        xb = x[b0 : b0 + 2]
+        per_batch.append([i3d_oracle.i3d_forward(xb[:, c].contiguous(), sd).numpy() for c in range(10)])
+    ref = host_oracle.stack_crop_outputs(per_batch)
+    assert rel_err(feats, ref) < TOL
+
+    out = str(tmp_path / "feats")
+    calls = []
+
+    def loader():
+        calls.append(1)
+        return clips
+
+    written = extract.extract([("vidA", loader), ("vidB", loader)], model, out, batch_size=4, max_crop_clips=16)
+    assert set(written) == {"vidA", "vidB"} and len(calls) == 2
+    again = extract.extract([("vidA", loader), ("vidC", loader)], model, out, batch_size=4, max_crop_clips=16)
+    assert set(again) == {"vidC"} and len(calls) == 3  # vidA skipped: file exists
+    np.testing.assert_array_equal(np.load(os.path.join(out, "vidA_i3d.npy")), np.load(os.path.join(out, "vidC_i3d.npy")))
+    seg = str(tmp_path / "seg32")
+    extract.segment(out, seg, 32)
+    got = np.load(os.path.join(seg, "vidA_i3d.npy"))
+    np.testing.assert_array_equal(got, host_oracle.segment_features(np.load(os.path.join(out, "vidA_i3d.npy")), 32))
+    assert got.shape == (10, 32, 2048)
+
+
+def test_stream_scores_match_oracle_end_to_end():
+    """ExtractScoreStream (backbone -> ring -> add_magnitude -> MGFN eval) on 2 tiny videos vs the
+    CPU oracle chain."""
+    from anomaly_detection_on_video_amd.i3d import I3Res50
+    from anomaly_detection_on_video_amd.models.mgfn import MGFNConfig, MGFNForVideoAnomalyDetection
+    from anomaly_detection_on_video_amd.pipeline import ExtractScoreStream
+    from oracle import host_oracle, i3d_oracle, mgfn_oracle
+
+    sd = synth_i3d_state_dict()
+    bb = I3Res50()
+    bb.load_state_dict(sd)
+    bb = bb.eval().to(DEV)
+    sc = MGFNForVideoAnomalyDetection(MGFNConfig())
+    msd = synth_module_state_dict(sc)
+    sc.load_state_dict(msd)
+    sc = sc.eval().to(DEV)
+    stream = ExtractScoreStream(bb, sc, clips_per_video=3, ncrops=2, local_batch=4)
+    x = synth_tensor("stream.x", (12, 3, 16, 48, 48), scale=2.0)  # 2 videos x 3 clips x 2 crops
+    scored = []
+    for i in range(0, 12, 4):
+        _g, s = stream.step(x[i : i + 4].to(DEV))
+        scored += s
+    assert [v for v, _ in scored] == [0, 1]
+    feats = i3d_oracle.i3d_forward(x, sd).reshape(12, 2048)
+    for v, s in scored:
+        f = feats[v * 6 : (v + 1) * 6].reshape(3, 2, 2048).numpy()
+        video = torch.from_numpy(host_oracle.add_magnitude(f)).unsqueeze(0).permute(0, 2, 1, 3)
+        ref = mgfn_oracle.mgfn_forward(video, msd).scores.reshape(-1)
+        assert rel_err(s.cpu(), ref) < TOL
