@@ -339,11 +339,12 @@ __global__ __launch_bounds__(256) void conv3d_igemm_f32_kernel(const ConvArgs a)
 // shadow.  Here every A element is one raw buffer load whose
 //   * per-lane voffset  = this thread's window origin (constant for the whole K loop),
 //   * scalar  soffset   = tap offset of row k from the gather table (SMEM/SALU),
-//   * validity          = one bit test of a per-thread tap mask built once per block (CHECK),
+//   * validity          = one masked compare against a per-thread coordinate mask built once per
+//                         block (CHECK): a tap is in range iff its dt, dh and dw each are,
 //                         realised as an out-of-range voffset -> the buffer unit returns 0;
 //                         convs whose every tap is in range for every m (1x1x1, no padding) skip
 //                         even that (CHECK = false): 0 VALU per element.
-// Requires: taps <= 32 when CHECK, x and packed weights each < 3.75 GiB (32-bit buffer offsets).
+// Requires: kernel extents <= 10 per axis, x < 3.75 GiB (32-bit buffer offsets).
 template <int BM, int BN, int BK, bool CHECK>
 __global__ __launch_bounds__(256) void conv3d_igemm_fast_kernel(const ConvArgs a) {
   using Cfg = IgemmCfg<BM, BN, BK>;
@@ -385,14 +386,11 @@ __global__ __launch_bounds__(256) void conv3d_igemm_fast_kernel(const ConvArgs a
     const int it0 = ot * a.st - a.pt, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
     vbase = (unsigned)(b * a.Cin * a.THW + it0 * a.HW + ih0 * a.W + iw0 + a.pad_off) * 4u;
     if constexpr (CHECK) {
-      int tap = 0;
-      for (int dt = 0; dt < a.kt_; ++dt)
-        for (int dh = 0; dh < a.kh_; ++dh)
-          for (int dw = 0; dw < a.kw_; ++dw, ++tap) {
-            const bool v = (unsigned)(it0 + dt) < (unsigned)a.T && (unsigned)(ih0 + dh) < (unsigned)a.H &&
-                           (unsigned)(iw0 + dw) < (unsigned)a.W;
-            vmask |= (v ? 1u : 0u) << tap;
-          }
+      // a tap (dt,dh,dw) is inside the input iff each coordinate is: keep one bit per coordinate
+      // value (bits 0-9: dt, 10-19: dh, 20-29: dw); the table holds the three bits a row needs
+      for (int dt = 0; dt < a.kt_; ++dt) vmask |= ((unsigned)(it0 + dt) < (unsigned)a.T ? 1u : 0u) << dt;
+      for (int dh = 0; dh < a.kh_; ++dh) vmask |= ((unsigned)(ih0 + dh) < (unsigned)a.H ? 1u : 0u) << (10 + dh);
+      for (int dw = 0; dw < a.kw_; ++dw) vmask |= ((unsigned)(iw0 + dw) < (unsigned)a.W ? 1u : 0u) << (20 + dw);
     }
   }
   const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) - a.pad_off, 0, a.x_bytes, 0x00020000);
@@ -405,7 +403,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_fast_kernel(const ConvArgs a
     for (int j = 0; j < RA; ++j) {
       const int2 e = ktab2[k0 + kr + KR * j];  // wave-uniform -> scalar loads; {byte offset, tap bit}
       unsigned voff = vbase;
-      if constexpr (CHECK) voff = (vmask & (unsigned)e.y) ? vbase : OOB;
+      if constexpr (CHECK) voff = ((vmask & (unsigned)e.y) == (unsigned)e.y) ? vbase : OOB;
       ra[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff, e.x, 0));
     }
 #pragma unroll
@@ -540,14 +538,14 @@ __global__ void build_ktab_kernel(int4* __restrict__ ktab, int kt, int kh, int k
       e = make_int4(0, 1 << 28, 0, 0);  // fails the temporal range check: contributes exact zeros
     }
     ktab[k] = e;
-    // second table for the fast kernel: {byte offset, tap bit (0 for padding rows)}
+    // second table for the fast kernel: {byte offset, required coordinate bits}; bit 30 is never
+    // set in a thread's mask, so padding rows (and kernels wider than 10) always read as zero
     int2* t2 = reinterpret_cast<int2*>(ktab + Kpad);
     int2 f;
-    if (k < K) {
-      const int tap = k % taps;
-      f = make_int2(e.x * 4, taps <= 32 ? (int)(1u << tap) : 0);
+    if (k < K && kt <= 10 && kh <= 10 && kw <= 10) {
+      f = make_int2(e.x * 4, (int)((1u << e.y) | (1u << (10 + e.z)) | (1u << (20 + e.w))));
     } else {
-      f = make_int2(0, 0);
+      f = make_int2(0, (int)(1u << 30));
     }
     t2[k] = f;
   }
@@ -642,10 +640,10 @@ static void tile_of(int algo, int* BM, int* BN, int* BK) {
   *BK = algo >= ADVHIP_ALGO_IGEMM_128x128x32 ? 32 : 16;
 }
 
-// the fast kernel covers convs with <= 32 taps on tensors addressable by 32-bit byte offsets
+// the fast kernel covers kernels up to 10x10x10 on tensors addressable by 32-bit byte offsets
 static bool fast_ok(const advhip_conv3d_desc* d, long long in_elems, long long w_elems) {
   const long long pad_off = (long long)d->pt * d->H * d->W + (long long)d->ph * d->W + d->pw;
-  return d->kt * d->kh * d->kw <= 32 && (in_elems + pad_off) * 4 < 0xF0000000ll && w_elems * 4 < 0xF0000000ll;
+  return d->kt <= 10 && d->kh <= 10 && d->kw <= 10 && (in_elems + pad_off) * 4 < 0xF0000000ll && w_elems * 4 < 0xF0000000ll;
 }
 
 // Heuristic used when the caller does not pin algo/splits (the Python engine normally pins both
@@ -740,7 +738,7 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
   ADVHIP_REQUIRE(base_algo >= ADVHIP_ALGO_IGEMM_128x128 && base_algo <= ADVHIP_ALGO_IGEMM_64x128x32, "conv3d: unknown algo %d", c.algo);
   if (fast) {
     ADVHIP_REQUIRE(fast_ok(d, in_elems, (long long)g.Kpad * d->Cout),
-                   "conv3d: fast kernel needs <= 32 taps and < 3.75 GiB operands (taps=%d)", d->kt * d->kh * d->kw);
+                   "conv3d: fast kernel needs kernel extents <= 10 and < 3.75 GiB operands (k=%d,%d,%d)", d->kt, d->kh, d->kw);
     a.kt_ = d->kt; a.kh_ = d->kh; a.kw_ = d->kw;
     a.pad_off = d->pt * d->H * d->W + d->ph * d->W + d->pw;
     a.x_bytes = (unsigned)((in_elems + a.pad_off) * 4);

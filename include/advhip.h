@@ -42,7 +42,7 @@ extern "C" {
 #define ADVHIP_ALGO_IGEMM_128x64x32 6
 #define ADVHIP_ALGO_IGEMM_64x64x32 7
 #define ADVHIP_ALGO_IGEMM_64x128x32 8
-/* + tile id 1..8: same tiles, gather arithmetic hoisted to scalar offsets + tap bit-mask (<= 32 taps) */
+/* + tile id 1..8: same tiles, gather arithmetic hoisted to scalar offsets + coordinate bit-mask (kernel <= 10^3) */
 #define ADVHIP_ALGO_FAST_BASE 32
 #define ADVHIP_ALGO_STEM 16 /* dedicated Cin=3 k(5,7,7) s2 kernel, LDS halo tile */
 

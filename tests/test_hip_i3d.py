@@ -85,8 +85,6 @@ def _skip_algo(algo, cout, k):
     base = algo - 32 if algo >= 32 else algo
     if base in (1, 4, 5, 8) and cout % 128:
         pytest.skip("Cout not a multiple of the 128-wide N tile")
-    if algo >= 32 and k[0] * k[1] * k[2] > 32:
-        pytest.skip("fast kernel covers <= 32 taps")
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])

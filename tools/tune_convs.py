@@ -67,7 +67,7 @@ def main():
             kpad = pc.w_packed.shape[0]
             cands = []
             taps = pc.kernel[0] * pc.kernel[1] * pc.kernel[2]
-            for algo in _lib.IGEMM_ALGOS + (_lib.FAST_ALGOS if taps <= 32 else ()):
+            for algo in _lib.IGEMM_ALGOS + _lib.FAST_ALGOS:
                 bm, bn, bk = _lib.algo_tile(algo)
                 if pc.cout % bn:
                     continue
