@@ -398,21 +398,29 @@ __global__ __launch_bounds__(256) void conv3d_igemm_fast_kernel(const ConvArgs a
   const int2* __restrict__ ktab2 = reinterpret_cast<const int2*>(a.ktab + a.Kpad);
   float ra[RA];
   float rb[RB][4];
+  // One k-step's share of the next tile's loads (issued between the MFMA groups of the current
+  // tile so their scalar loads / mask tests / VMEM issue sit in the MFMAs' shadow instead of in
+  // front of them).
+  constexpr int KS = BK / 4;                       // k-steps per tile
+  constexpr int A_PER_KS = (RA + KS - 1) / KS;     // gathers issued per k-step
+  constexpr int B_PER_KS = (RB + KS - 1) / KS;
+  auto load_a = [&](int k0, int j) {
+    const int2 e = ktab2[k0 + kr + KR * j];  // wave-uniform -> scalar loads; {byte offset, coordinate bits}
+    unsigned voff = vbase;
+    if constexpr (CHECK) voff = ((vmask & (unsigned)e.y) == (unsigned)e.y) ? vbase : OOB;
+    ra[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff, e.x, 0));
+  };
+  auto load_b = [&](int k0, int j) {
+    const int idx = tid + 256 * j;
+    const int row = idx / (BN / 4), c4 = idx % (BN / 4);
+    const float4 t = *reinterpret_cast<const float4*>(a.w + (size_t)(k0 + row) * a.Cout + n0 + c4 * 4);
+    rb[j][0] = t.x; rb[j][1] = t.y; rb[j][2] = t.z; rb[j][3] = t.w;
+  };
   auto load_tiles = [&](int k0) {
 #pragma unroll
-    for (int j = 0; j < RA; ++j) {
-      const int2 e = ktab2[k0 + kr + KR * j];  // wave-uniform -> scalar loads; {byte offset, tap bit}
-      unsigned voff = vbase;
-      if constexpr (CHECK) voff = ((vmask & (unsigned)e.y) == (unsigned)e.y) ? vbase : OOB;
-      ra[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff, e.x, 0));
-    }
+    for (int j = 0; j < RA; ++j) load_a(k0, j);
 #pragma unroll
-    for (int j = 0; j < RB; ++j) {
-      const int idx = tid + 256 * j;
-      const int row = idx / (BN / 4), c4 = idx % (BN / 4);
-      const float4 t = *reinterpret_cast<const float4*>(a.w + (size_t)(k0 + row) * a.Cout + n0 + c4 * 4);
-      rb[j][0] = t.x; rb[j][1] = t.y; rb[j][2] = t.z; rb[j][3] = t.w;
-    }
+    for (int j = 0; j < RB; ++j) load_b(k0, j);
   };
   auto store_tiles = [&](int buf) {
 #pragma unroll
@@ -446,31 +454,47 @@ __global__ __launch_bounds__(256) void conv3d_igemm_fast_kernel(const ConvArgs a
   __syncthreads();
   for (int kt = kt0; kt < kt1; ++kt) {
     const int cur = (kt - kt0) & 1;
-    if (kt + 1 < kt1) load_tiles((kt + 1) * BK);
-#pragma unroll
-    for (int ks = 0; ks < BK / 4; ++ks) {
-      float av[FM], bv[FN];
+    // straight-line body (one scheduling region): the last iteration re-loads its own tile into the
+    // idle buffer instead of branching around the prefetch
+    const int knext = (kt + 1 < kt1 ? kt + 1 : kt) * BK;
+    float av[2][FM], bv[2][FN];
+    auto read_frags = [&](int ks, float (&ao)[FM], float (&bo)[FN]) {
       if constexpr (FM == 4) {
         const float4 t = *reinterpret_cast<const float4*>(&As[cur][4 * ks + lg][a_col]);
-        av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
+        ao[0] = t.x; ao[1] = t.y; ao[2] = t.z; ao[3] = t.w;
       } else {
         const float2 t = *reinterpret_cast<const float2*>(&As[cur][4 * ks + lg][a_col]);
-        av[0] = t.x; av[1] = t.y;
+        ao[0] = t.x; ao[1] = t.y;
       }
       if constexpr (FN == 4) {
         const float4 t = *reinterpret_cast<const float4*>(&Bs[cur][4 * ks + lg][b_col]);
-        bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
+        bo[0] = t.x; bo[1] = t.y; bo[2] = t.z; bo[3] = t.w;
       } else {
         const float2 t = *reinterpret_cast<const float2*>(&Bs[cur][4 * ks + lg][b_col]);
-        bv[0] = t.x; bv[1] = t.y;
+        bo[0] = t.x; bo[1] = t.y;
       }
+    };
+    read_frags(0, av[0], bv[0]);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      // operands of the next k-step are requested before this step's MFMAs (LDS latency hidden)
+      if (ks + 1 < KS) read_frags(ks + 1, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
+#pragma unroll
+      for (int j = 0; j < A_PER_KS; ++j)
+        if (ks * A_PER_KS + j < RA) load_a(knext, ks * A_PER_KS + j);
+#pragma unroll
+      for (int j = 0; j < B_PER_KS; ++j)
+        if (ks * B_PER_KS + j < RB) load_b(knext, ks * B_PER_KS + j);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks & 1][i], bv[ks & 1][j], acc[i][j], 0, 0, 0);
+      // keep each k-step's share of the prefetch next to its MFMAs (hipcc otherwise sinks all the
+      // loads to the end of the tile, right in front of the ds_writes that wait for them)
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (kt + 1 < kt1) store_tiles(cur ^ 1);
+    store_tiles(cur ^ 1);
     __syncthreads();
   }
   igemm_epilogue<BM, BN, BK>(a, acc, smem, split, m0, n0, wave, lane);
