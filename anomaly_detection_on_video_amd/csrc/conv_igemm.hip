@@ -402,10 +402,17 @@ __global__ __launch_bounds__(256) void conv3d_igemm_fast_kernel(const ConvArgs a
   // tile so their scalar loads / mask tests / VMEM issue sit in the MFMAs' shadow instead of in
   // front of them).
   constexpr int KS = BK / 4;                       // k-steps per tile
-  constexpr int A_PER_KS = (RA + KS - 1) / KS;     // gathers issued per k-step
+  // the table entries of a tile are fetched (scalar loads) during k-step 0 and consumed by the
+  // gathers of k-steps 1..KS-1, so no MFMA group waits on SMEM latency
+  constexpr int A_PER_KS = (RA + KS - 2) / (KS - 1);
   constexpr int B_PER_KS = (RB + KS - 1) / KS;
-  auto load_a = [&](int k0, int j) {
-    const int2 e = ktab2[k0 + kr + KR * j];  // wave-uniform -> scalar loads; {byte offset, coordinate bits}
+  int2 ent[RA];
+  auto load_entries = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < RA; ++j) ent[j] = ktab2[k0 + kr + KR * j];  // wave-uniform -> scalar loads
+  };
+  auto load_a = [&](int j) {
+    const int2 e = ent[j];  // {byte offset, coordinate bits}
     unsigned voff = vbase;
     if constexpr (CHECK) voff = ((vmask & (unsigned)e.y) == (unsigned)e.y) ? vbase : OOB;
     ra[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff, e.x, 0));
@@ -417,8 +424,9 @@ __global__ __launch_bounds__(256) void conv3d_igemm_fast_kernel(const ConvArgs a
     rb[j][0] = t.x; rb[j][1] = t.y; rb[j][2] = t.z; rb[j][3] = t.w;
   };
   auto load_tiles = [&](int k0) {
+    load_entries(k0);
 #pragma unroll
-    for (int j = 0; j < RA; ++j) load_a(k0, j);
+    for (int j = 0; j < RA; ++j) load_a(j);
 #pragma unroll
     for (int j = 0; j < RB; ++j) load_b(k0, j);
   };
@@ -479,9 +487,10 @@ __global__ __launch_bounds__(256) void conv3d_igemm_fast_kernel(const ConvArgs a
     for (int ks = 0; ks < KS; ++ks) {
       // operands of the next k-step are requested before this step's MFMAs (LDS latency hidden)
       if (ks + 1 < KS) read_frags(ks + 1, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
+      if (ks == 0) load_entries(knext);
 #pragma unroll
       for (int j = 0; j < A_PER_KS; ++j)
-        if (ks * A_PER_KS + j < RA) load_a(knext, ks * A_PER_KS + j);
+        if (ks >= 1 && (ks - 1) * A_PER_KS + j < RA) load_a((ks - 1) * A_PER_KS + j);
 #pragma unroll
       for (int j = 0; j < B_PER_KS; ++j)
         if (ks * B_PER_KS + j < RB) load_b(knext, ks * B_PER_KS + j);
