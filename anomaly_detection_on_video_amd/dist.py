@@ -55,7 +55,10 @@ def all_gather_rows(local: torch.Tensor, group=None) -> torch.Tensor:
         return local
     world = dist.get_world_size(group)
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
-    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    if dist.get_backend(group) == "gloo":  # CPU tests / single-GPU rehearsal: gloo has no flat all-gather
+        dist.all_gather(list(out.chunk(world, dim=0)), local.contiguous(), group=group)
+    else:
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
     return out
 
 

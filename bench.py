@@ -105,7 +105,12 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
-    adist.init_process_group("nccl")
+    # ADV_BENCH_SHARE_GPU=1 (rehearsal only): every rank uses cuda:0 and the collective runs over gloo,
+    # so the N>1 code path can be exercised on a one-GPU box; never used for reported numbers
+    rehearsal = os.environ.get("ADV_BENCH_SHARE_GPU") == "1"
+    if rehearsal:
+        local_rank = 0
+    adist.init_process_group("gloo" if rehearsal else "nccl")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -184,7 +189,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share one GPU, gloo)",
             "config": {
                 "workload": "I3D-RGB feature extraction, batch=32 clips, 1xMI355X (HIP conv3d + fused BN/ReLU) -> MGFN MIL score per 32-clip x 10-crop video"
                 if world == 1 else
