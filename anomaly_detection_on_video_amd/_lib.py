@@ -29,10 +29,14 @@ ALGO_STEM = 16
 ALGO_FAST_BASE = 32  # + tile id: scalar-offset / tap-mask gather (<= 32 taps)
 IGEMM_ALGOS = (1, 2, 3, 4, 5, 6, 7, 8)
 FAST_ALGOS = tuple(ALGO_FAST_BASE + a for a in IGEMM_ALGOS)
+ALGO_DMA_BASE = 64  # + tile id: fast gather + LDS-DMA staging into a 3-deep ring (no 128x128x32)
+DMA_ALGOS = tuple(ALGO_DMA_BASE + a for a in (1, 2, 3, 4, 6, 7, 8))
 
 
 def algo_tile(algo: int):
     """(BM, BN, BK) of an implicit-GEMM algorithm id."""
+    if algo >= ALGO_DMA_BASE:
+        algo -= ALGO_DMA_BASE
     if algo >= ALGO_FAST_BASE:
         algo -= ALGO_FAST_BASE
     t = (algo - 1) & 3

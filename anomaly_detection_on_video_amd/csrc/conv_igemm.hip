@@ -20,6 +20,7 @@
 // /root/reference/src/i3d.py:98-121, 262-272, 303-305.
 #include <algorithm>
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -46,6 +47,7 @@ struct ConvArgs {
   int kt_, kh_, kw_;  // kernel extents (tap decode)
   int pad_off;        // pt*HW + ph*W + pw: makes every per-lane window origin offset non-negative
   unsigned x_bytes;   // buffer range of x (plus pad_off*4)
+  unsigned w_bytes;   // buffer range of the packed weights (LDS-DMA kernel)
 };
 
 template <int VW>
@@ -509,6 +511,212 @@ __global__ __launch_bounds__(256) void conv3d_igemm_fast_kernel(const ConvArgs a
   igemm_epilogue<BM, BN, BK>(a, acc, smem, split, m0, n0, wave, lane);
 }
 
+// ================================================================================================
+// LDS-DMA variant of the fast kernel: operand tiles go HBM/L2 -> LDS directly
+// (`buffer_load_dword ... lds` for the gathered A rows, `buffer_load_dwordx4 ... lds` for the packed
+// weight rows) into a 3-deep ring, so there are no staging VGPRs, no ds_write, and two k-tiles stay
+// in flight across the single barrier per k-tile (counted vmcnt).
+template <int BM, int BN, int BK>
+struct DmaCfg {
+  static constexpr int KR = 256 / BM;
+  static constexpr int LA = BK / KR;                 // A LDS-DMA instructions per wave per k-tile
+  static constexpr int LB = BK * BN * 4 / 1024 / 4;  // B (16-byte) LDS-DMA instructions per wave per k-tile
+  static constexpr int STAGE = BK * (BM + BN);       // floats per ring stage
+};
+
+using lds_ptr_t = __attribute__((address_space(3))) void*;
+using i32x8 = __attribute__((ext_vector_type(8))) int;
+using i32x16 = __attribute__((ext_vector_type(16))) int;
+
+// N consecutive {byte offset, coordinate bits} table entries through the scalar cache.  Inline asm
+// (load + wait in one statement) because hipcc will not use SMEM for a table it cannot prove
+// unclobbered next to LDS-DMA "stores" and falls back to vector loads + waterfall loops.
+template <int N>
+__device__ __forceinline__ void sload_entries(const int2* base, int byte_off, int (&out)[2 * N]) {
+  static_assert(N == 4 || N == 8 || N == 16, "entries per wave per k-tile");
+  if constexpr (N == 4) {
+    i32x8 v;
+    asm volatile("s_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(base), "s"(byte_off) : "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = v[i];
+  } else if constexpr (N == 8) {
+    i32x16 v;
+    asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(base), "s"(byte_off) : "memory");
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[i] = v[i];
+  } else {
+    i32x16 v, w;
+    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(v), "=&s"(w) : "s"(base), "s"(byte_off), "s"(byte_off + 64) : "memory");
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { out[i] = v[i]; out[16 + i] = w[i]; }
+  }
+}
+
+// LDS fragment reads as inline asm: hipcc tracks pending LDS-DMA writes per LDS object only for a
+// handful of DMA instructions and otherwise puts `s_waitcnt vmcnt(0)` in front of every ds_read that
+// follows an LDS-DMA, which would drain the ring every k-tile.  Reads issued from asm are invisible
+// to that pass; their completion is waited for by hand (lds_wait names the destinations so that
+// neither the MFMAs nor a register copy can be scheduled above the wait).
+template <int NF>
+struct Frag;  // NF fp32 operands of one k-step (4 -> ds_read_b128, 2 -> ds_read_b64)
+template <>
+struct Frag<4> { f32x4 v; };
+template <>
+struct Frag<2> { __attribute__((ext_vector_type(2))) float v; };
+
+template <int NF, int OFF>
+__device__ __forceinline__ void lds_read(Frag<NF>& f, unsigned addr) {
+  if constexpr (NF == 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.v) : "v"(addr), "n"(OFF));
+  else asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(f.v) : "v"(addr), "n"(OFF));
+}
+template <int CNT, int NA, int NB>
+__device__ __forceinline__ void lds_wait(Frag<NA>& a, Frag<NB>& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a.v), "+v"(b.v) : "n"(CNT));
+}
+
+template <int BM, int BN, int BK, bool CHECK>
+__global__ __launch_bounds__(256) void conv3d_igemm_dma_kernel(const ConvArgs a) {
+  using Cfg = IgemmCfg<BM, BN, BK>;
+  using D = DmaCfg<BM, BN, BK>;
+  constexpr int FM = Cfg::FM, FN = Cfg::FN, KR = D::KR, LA = D::LA, LB = D::LB, KS = BK / 4;
+  static_assert(LB >= 1 && LA >= 1 && LA + LB <= 31, "tile / vmcnt budget");
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  constexpr int RING = 3 * D::STAGE;
+  constexpr int SMEM = RING > Cfg::ST_FLOATS ? RING : Cfg::ST_FLOATS;
+
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = a.tiles_m * a.tiles_n;
+  int L, split;
+  if (a.splits > 1) {
+    split = blockIdx.x % a.splits;
+    L = blockIdx.x / a.splits;
+  } else {
+    split = 0;
+    L = xcd_remap(blockIdx.x, ntiles);
+  }
+  const int tile_n = L % a.tiles_n, tile_m = L / a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int ml = tid % BM;
+  const int kr = __builtin_amdgcn_readfirstlane(tid / BM);
+  const int m = m0 + ml;
+  unsigned vbase = OOB;
+  unsigned vmask = 0;
+  if (m < a.M) {
+    const int b = m / a.THWo;
+    const int p = m - b * a.THWo;
+    const int ot = p / a.HWo;
+    const int q = p - ot * a.HWo;
+    const int oh = q / a.Wo;
+    const int ow = q - oh * a.Wo;
+    const int it0 = ot * a.st - a.pt, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
+    vbase = (unsigned)(b * a.Cin * a.THW + it0 * a.HW + ih0 * a.W + iw0 + a.pad_off) * 4u;
+    if constexpr (CHECK) {
+      for (int dt = 0; dt < a.kt_; ++dt) vmask |= ((unsigned)(it0 + dt) < (unsigned)a.T ? 1u : 0u) << dt;
+      for (int dh = 0; dh < a.kh_; ++dh) vmask |= ((unsigned)(ih0 + dh) < (unsigned)a.H ? 1u : 0u) << (10 + dh);
+      for (int dw = 0; dw < a.kw_; ++dw) vmask |= ((unsigned)(iw0 + dw) < (unsigned)a.W ? 1u : 0u) << (20 + dw);
+    }
+  }
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) - a.pad_off, 0, a.x_bytes, 0x00020000);
+  const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+  const int2* __restrict__ ktab2 = reinterpret_cast<const int2*>(a.ktab + a.Kpad);
+  // B rows: a wave's 64 lanes x 16 B cover RPW consecutive k-rows of the [BK][BN] tile
+  constexpr int LPRB = BN / 4;
+  constexpr int RPW = 64 / LPRB;
+  const unsigned wvoff = (unsigned)((lane / LPRB) * a.Cout + (lane % LPRB) * 4) * 4u;
+  const int a_wave_col = (wave % (BM / 64)) * 64;  // which 64-float piece of an A row this wave fills
+
+  // wave group kr fills k-rows [kr*LA, (kr+1)*LA) of a tile: its table entries are contiguous
+  auto issue_tile = [&](int k0, int stage) {
+    float* As = smem + stage * D::STAGE;
+    float* Bs = As + BK * BM;
+    int ent[2 * LA];
+    sload_entries<LA>(ktab2, (k0 + kr * LA) * 8, ent);
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+      const int krow = kr * LA + j;
+      unsigned voff = vbase;
+      if constexpr (CHECK) voff = ((vmask & (unsigned)ent[2 * j + 1]) == (unsigned)ent[2 * j + 1]) ? vbase : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(As + krow * BM + a_wave_col), 4, voff, ent[2 * j], 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+      const int row0 = (wave * LB + j) * RPW;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(Bs + row0 * BN), 16, wvoff, ((k0 + row0) * a.Cout + n0) * 4, 0, 0);
+    }
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lg = lane >> 4;
+  const int a_col = wm * Cfg::WM + FM * li;
+  const int b_col = wn * Cfg::WN + FN * li;
+  // per-lane LDS byte addresses of the k-step-0 fragments in ring stage 0
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+  const unsigned a_addr0 = lds0 + (unsigned)(lg * BM + a_col) * 4u;
+  const unsigned b_addr0 = lds0 + (unsigned)(BK * BM + lg * BN + b_col) * 4u;
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto mfma_step = [&](const Frag<FM>& fa, const Frag<FN>& fb) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.v[i], fb.v[j], acc[i][j], 0, 0, 0);
+  };
+
+  // k-step ks of a stage sits ks*4 rows further down both tiles -> immediate offsets
+  auto compute = [&](int stage) {
+    const unsigned aa = a_addr0 + (unsigned)(stage * D::STAGE) * 4u;
+    const unsigned ba = b_addr0 + (unsigned)(stage * D::STAGE) * 4u;
+    Frag<FM> fa[2];
+    Frag<FN> fb[2];
+    lds_read<FM, 0>(fa[0], aa);
+    lds_read<FN, 0>(fb[0], ba);
+    auto body = [&](auto ks_c) {
+      constexpr int ks = decltype(ks_c)::value;
+      if constexpr (ks + 1 < KS) {
+        lds_read<FM, (ks + 1) * 4 * BM * 4>(fa[(ks + 1) & 1], aa);
+        lds_read<FN, (ks + 1) * 4 * BN * 4>(fb[(ks + 1) & 1], ba);
+        lds_wait<2>(fa[ks & 1], fb[ks & 1]);  // the two reads of step ks+1 may stay in flight
+      } else {
+        lds_wait<0>(fa[ks & 1], fb[ks & 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(fa[ks & 1], fb[ks & 1]);
+    };
+    [&]<int... I>(std::integer_sequence<int, I...>) { (body(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, KS>{});
+  };
+
+  const int nk_all = a.Kpad / BK;
+  const int kt0 = (nk_all * split) / a.splits;
+  const int kt1 = (nk_all * (split + 1)) / a.splits;
+  // prologue: two k-tiles in flight
+  if (kt0 < kt1) issue_tile(kt0 * BK, 0);
+  if (kt0 + 1 < kt1) issue_tile((kt0 + 1) * BK, 1);
+  int stage = 0;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    // tile kt has landed once at most the next tile's LA+LB loads are still outstanding
+    if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA + LB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");  // all waves' parts of tile kt are in LDS; stage (kt-1)%3 is free
+    if (kt + 2 < kt1) issue_tile((kt + 2) * BK, stage == 0 ? 2 : stage - 1);
+    compute(stage);
+    stage = stage == 2 ? 0 : stage + 1;
+  }
+  __syncthreads();  // every wave is done with the ring before the epilogue reuses it as staging
+  igemm_epilogue<BM, BN, BK>(a, acc, smem, split, m0, n0, wave, lane);
+}
+
 // y = act(sum_s slab[s] * scale[c] + shift[c] (+ res)), slabs in NCDHW like y
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ scale,
                                      const float* __restrict__ shift, const float* __restrict__ res,
@@ -666,6 +874,7 @@ struct Choice {
 };
 
 static void tile_of(int algo, int* BM, int* BN, int* BK) {
+  if (algo >= ADVHIP_ALGO_DMA_BASE) algo -= ADVHIP_ALGO_DMA_BASE;
   if (algo >= ADVHIP_ALGO_FAST_BASE) algo -= ADVHIP_ALGO_FAST_BASE;
   const int t = (algo - 1) & 3;
   *BM = (t == 0 || t == 1) ? 128 : 64;
@@ -766,8 +975,8 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
   const Choice c = choose(d, M, g.Kpad);
   int BM, BN, BK;
   tile_of(c.algo, &BM, &BN, &BK);
-  const bool fast = c.algo >= ADVHIP_ALGO_FAST_BASE;
-  const int base_algo = fast ? c.algo - ADVHIP_ALGO_FAST_BASE : c.algo;
+  const bool fast = c.algo >= ADVHIP_ALGO_FAST_BASE;  // includes the LDS-DMA ids
+  const int base_algo = c.algo >= ADVHIP_ALGO_DMA_BASE ? c.algo - ADVHIP_ALGO_DMA_BASE : (fast ? c.algo - ADVHIP_ALGO_FAST_BASE : c.algo);
   ADVHIP_REQUIRE(base_algo >= ADVHIP_ALGO_IGEMM_128x128 && base_algo <= ADVHIP_ALGO_IGEMM_64x128x32, "conv3d: unknown algo %d", c.algo);
   if (fast) {
     ADVHIP_REQUIRE(fast_ok(d, in_elems, (long long)g.Kpad * d->Cout),
@@ -775,6 +984,7 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
     a.kt_ = d->kt; a.kh_ = d->kh; a.kw_ = d->kw;
     a.pad_off = d->pt * d->H * d->W + d->ph * d->W + d->pw;
     a.x_bytes = (unsigned)((in_elems + a.pad_off) * 4);
+    a.w_bytes = (unsigned)((long long)g.Kpad * d->Cout * 4);
   }
   ADVHIP_REQUIRE(d->Cout % BN == 0, "conv3d: Cout=%d not a multiple of the %d-wide N tile", d->Cout, BN);
   ADVHIP_REQUIRE(g.Kpad % BK == 0 || BK == 16, "conv3d: internal: Kpad");
@@ -803,7 +1013,19 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
     if (nocheck) hipLaunchKernelGGL((conv3d_igemm_fast_kernel<BM_, BN_, BK_, false>), grid, dim3(256), 0, st, a);   \
     else hipLaunchKernelGGL((conv3d_igemm_fast_kernel<BM_, BN_, BK_, true>), grid, dim3(256), 0, st, a);            \
     break;
+#define ADVHIP_DMA_CASE(ID, BM_, BN_, BK_)                                                                        \
+  case ADVHIP_ALGO_DMA_BASE + ID:                                                                                 \
+    if (nocheck) hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, false>), grid, dim3(256), 0, st, a);  \
+    else hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, true>), grid, dim3(256), 0, st, a);           \
+    break;
   switch (c.algo) {
+    ADVHIP_DMA_CASE(ADVHIP_ALGO_IGEMM_128x128, 128, 128, 16)
+    ADVHIP_DMA_CASE(ADVHIP_ALGO_IGEMM_128x64, 128, 64, 16)
+    ADVHIP_DMA_CASE(ADVHIP_ALGO_IGEMM_64x64, 64, 64, 16)
+    ADVHIP_DMA_CASE(ADVHIP_ALGO_IGEMM_64x128, 64, 128, 16)
+    ADVHIP_DMA_CASE(ADVHIP_ALGO_IGEMM_128x64x32, 128, 64, 32)
+    ADVHIP_DMA_CASE(ADVHIP_ALGO_IGEMM_64x64x32, 64, 64, 32)
+    ADVHIP_DMA_CASE(ADVHIP_ALGO_IGEMM_64x128x32, 64, 128, 32)
     ADVHIP_FAST_CASE(ADVHIP_ALGO_IGEMM_128x128, 128, 128, 16)
     ADVHIP_FAST_CASE(ADVHIP_ALGO_IGEMM_128x64, 128, 64, 16)
     ADVHIP_FAST_CASE(ADVHIP_ALGO_IGEMM_64x64, 64, 64, 16)

@@ -44,6 +44,8 @@ extern "C" {
 #define ADVHIP_ALGO_IGEMM_64x128x32 8
 /* + tile id 1..8: same tiles, gather arithmetic hoisted to scalar offsets + coordinate bit-mask (kernel <= 10^3) */
 #define ADVHIP_ALGO_FAST_BASE 32
+/* + tile id: the fast gather with LDS-DMA operand staging into a 3-deep ring (no 128x128x32) */
+#define ADVHIP_ALGO_DMA_BASE 64
 #define ADVHIP_ALGO_STEM 16 /* dedicated Cin=3 k(5,7,7) s2 kernel, LDS halo tile */
 
 typedef struct advhip_conv3d_desc {

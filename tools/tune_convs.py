@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                   "anomaly_detection_on_video_amd", "tuned", "gfx950.json"))
     ap.add_argument("--report", default="")
+    ap.add_argument("--quick", action="store_true", help="skip the generic-gather variants")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     os.environ["ADV_NO_TUNED"] = "1"
@@ -67,7 +68,7 @@ def main():
             kpad = pc.w_packed.shape[0]
             cands = []
             taps = pc.kernel[0] * pc.kernel[1] * pc.kernel[2]
-            for algo in _lib.IGEMM_ALGOS + _lib.FAST_ALGOS:
+            for algo in ((3,) if args.quick else _lib.IGEMM_ALGOS) + _lib.FAST_ALGOS + _lib.DMA_ALGOS:
                 bm, bn, bk = _lib.algo_tile(algo)
                 if pc.cout % bn:
                     continue
