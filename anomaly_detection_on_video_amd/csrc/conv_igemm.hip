@@ -631,14 +631,15 @@ __global__ __launch_bounds__(256) void conv3d_igemm_dma_kernel(const ConvArgs a)
   const unsigned wvoff = (unsigned)((lane / LPRB) * a.Cout + (lane % LPRB) * 4) * 4u;
   const int a_wave_col = (wave % (BM / 64)) * 64;  // which 64-float piece of an A row this wave fills
 
-  // wave group kr fills k-rows [kr*LA, (kr+1)*LA) of a tile: its table entries are contiguous
-  auto issue_tile = [&](int k0, int stage) {
+  // wave group kr fills k-rows [kr*LA, (kr+1)*LA) of a tile: its table entries are contiguous.
+  // A tile's loads are issued in KS slices (issue_part) so they can sit between the MFMA groups.
+  int ent[2 * LA];
+  auto issue_part = [&](int k0, int stage, int part, int nparts) {
     float* As = smem + stage * D::STAGE;
     float* Bs = As + BK * BM;
-    int ent[2 * LA];
-    sload_entries<LA>(ktab2, (k0 + kr * LA) * 8, ent);
 #pragma unroll
     for (int j = 0; j < LA; ++j) {
+      if (j * nparts / LA != part) continue;
       const int krow = kr * LA + j;
       unsigned voff = vbase;
       if constexpr (CHECK) voff = ((vmask & (unsigned)ent[2 * j + 1]) == (unsigned)ent[2 * j + 1]) ? vbase : OOB;
@@ -646,9 +647,14 @@ __global__ __launch_bounds__(256) void conv3d_igemm_dma_kernel(const ConvArgs a)
     }
 #pragma unroll
     for (int j = 0; j < LB; ++j) {
+      if (j * nparts / LB != part) continue;
       const int row0 = (wave * LB + j) * RPW;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(Bs + row0 * BN), 16, wvoff, ((k0 + row0) * a.Cout + n0) * 4, 0, 0);
     }
+  };
+  auto issue_tile = [&](int k0, int stage) {
+    sload_entries<LA>(ktab2, (k0 + kr * LA) * 8, ent);
+    issue_part(k0, stage, 0, 1);
   };
 
   const int wm = wave >> 1, wn = wave & 1;
@@ -674,8 +680,10 @@ __global__ __launch_bounds__(256) void conv3d_igemm_dma_kernel(const ConvArgs a)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.v[i], fb.v[j], acc[i][j], 0, 0, 0);
   };
 
-  // k-step ks of a stage sits ks*4 rows further down both tiles -> immediate offsets
-  auto compute = [&](int stage) {
+  // k-step ks of a stage sits ks*4 rows further down both tiles -> immediate offsets.
+  // `pre` >= 0: also issue tile (pre) into ring stage `pstage`, one slice per k-step.
+  auto compute = [&](auto pre_c, int stage, int pre_k0, int pstage) {
+    constexpr bool PRE = decltype(pre_c)::value;
     const unsigned aa = a_addr0 + (unsigned)(stage * D::STAGE) * 4u;
     const unsigned ba = b_addr0 + (unsigned)(stage * D::STAGE) * 4u;
     Frag<FM> fa[2];
@@ -692,7 +700,9 @@ __global__ __launch_bounds__(256) void conv3d_igemm_dma_kernel(const ConvArgs a)
         lds_wait<0>(fa[ks & 1], fb[ks & 1]);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (PRE) issue_part(pre_k0, pstage, ks, KS);
       mfma_step(fa[ks & 1], fb[ks & 1]);
+      __builtin_amdgcn_sched_barrier(0);
     };
     [&]<int... I>(std::integer_sequence<int, I...>) { (body(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, KS>{});
   };
@@ -709,8 +719,12 @@ __global__ __launch_bounds__(256) void conv3d_igemm_dma_kernel(const ConvArgs a)
     if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA + LB) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");  // all waves' parts of tile kt are in LDS; stage (kt-1)%3 is free
-    if (kt + 2 < kt1) issue_tile((kt + 2) * BK, stage == 0 ? 2 : stage - 1);
-    compute(stage);
+    if (kt + 2 < kt1) {
+      sload_entries<LA>(ktab2, ((kt + 2) * BK + kr * LA) * 8, ent);
+      compute(std::true_type{}, stage, (kt + 2) * BK, stage == 0 ? 2 : stage - 1);
+    } else {
+      compute(std::false_type{}, stage, 0, 0);
+    }
     stage = stage == 2 ? 0 : stage + 1;
   }
   __syncthreads();  // every wave is done with the ring before the epilogue reuses it as staging
