@@ -33,6 +33,68 @@ __global__ void maxpool3d_kernel(const float* __restrict__ x, float* __restrict_
   }
 }
 
+// Specialisation for the stem pool k(2,3,3) s(2,2,2) on rows of <= 128 floats (W even): one
+// wavefront per output row.  Each of the 2x3 input rows is read once as a coalesced float2 per lane
+// (columns 2l, 2l+1); the third column of a window comes from the next lane by shuffle, so every
+// input element is loaded by at most two waves (vs 2.25 scattered dword loads per element before).
+__global__ __launch_bounds__(256) void maxpool3d_233_kernel(const float* __restrict__ x, float* __restrict__ y, int T,
+                                                            int H, int W, int To, int Ho, int Wo, long long rows) {
+  const int lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);  // (bc, to, ho)
+  if (row >= rows) return;
+  const int ho = (int)(row % Ho);
+  const long long r = row / Ho;
+  const int to = (int)(r % To);
+  const long long bc = r / To;
+  const float* base = x + ((bc * T + 2 * to) * H + 2 * ho) * (long long)W;
+  const bool ld = 2 * lane + 1 < W;
+  float m = -INFINITY;
+  bool isnan_ = false;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      float2 v = make_float2(-INFINITY, -INFINITY);
+      if (ld) v = *reinterpret_cast<const float2*>(base + ((long long)a * H + b) * W + 2 * lane);
+      const float nx = __shfl_down(v.x, 1, 64);  // column 2l+2
+      const float w3 = fmaxf(fmaxf(v.x, v.y), nx);
+      isnan_ |= (v.x != v.x) | (v.y != v.y) | (nx != nx);
+      m = fmaxf(m, w3);
+    }
+  if (lane < Wo) y[row * Wo + lane] = isnan_ ? NAN : m;  // torch's max pooling propagates NaN
+}
+
+// Temporal-only pooling (kh = kw = 1, sh = sw = 1): y[bc,to,p] = max_a x[bc, to*st + a, p]; four
+// independent outputs per thread keep more loads in flight.
+__global__ void maxpool3d_t_kernel(const float* __restrict__ x, float* __restrict__ y, int T, int HW, int To, int kt,
+                                   int st, long long total) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i0 = blockIdx.x * (long long)blockDim.x + threadIdx.x; i0 < total; i0 += 4 * stride) {
+    float m[4];
+    long long idx[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long i = i0 + u * stride;
+      idx[u] = i;
+      m[u] = -INFINITY;
+      if (i < total) {
+        const int p = (int)(i % HW);
+        const long long r = i / HW;
+        const int to = (int)(r % To);
+        const long long bc = r / To;
+        const float* q = x + ((bc * T + (long long)to * st) * HW) + p;
+        for (int a = 0; a < kt; ++a) {
+          const float v = q[(long long)a * HW];
+          m[u] = (v > m[u] || v != v) ? v : m[u];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (idx[u] < total) y[idx[u]] = m[u];
+  }
+}
+
 // One wavefront per row: lanes stride the row, then a 64-wide shuffle reduction.
 __global__ void global_avgpool_kernel(const float* __restrict__ x, float* __restrict__ y, long long rows, int n) {
   const int lane = threadIdx.x & 63;
@@ -58,6 +120,19 @@ extern "C" int advhip_maxpool3d_f32(const float* x, float* y, int32_t B, int32_t
                  "maxpool3d: bad shape (B=%d C=%d T=%d H=%d W=%d k=%d,%d,%d s=%d,%d,%d)", B, C, T, H, W, kt, kh, kw, st, sh, sw);
   const int To = (T - kt) / st + 1, Ho = (H - kh) / sh + 1, Wo = (W - kw) / sw + 1;
   const long long total = (long long)B * C * To * Ho * Wo;
+  if (kt == 2 && kh == 3 && kw == 3 && st == 2 && sh == 2 && sw == 2 && W % 2 == 0 && W <= 128 && Wo < 64) {
+    const long long rows = (long long)B * C * To * Ho;
+    const long long blocks = (rows + 3) / 4;
+    ADVHIP_REQUIRE(blocks < (1ll << 31), "maxpool3d: too many rows");
+    hipLaunchKernelGGL(maxpool3d_233_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, T, H, W, To,
+                       Ho, Wo, rows);
+    return check_launch("maxpool3d_233");
+  }
+  if (kh == 1 && kw == 1 && sh == 1 && sw == 1) {
+    const int grid = (int)std::min<long long>((total + 1023) / 1024, 256 * 16);
+    hipLaunchKernelGGL(maxpool3d_t_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, T, H * W, To, kt, st, total);
+    return check_launch("maxpool3d_t");
+  }
   const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 32);
   hipLaunchKernelGGL(maxpool3d_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, T, H, W, To, Ho, Wo, kt, kh,
                      kw, st, sh, sw, total);
