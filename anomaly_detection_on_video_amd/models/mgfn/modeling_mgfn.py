@@ -61,6 +61,40 @@ else:  # pragma: no cover
         scores: torch.Tensor = None
 
 
+# ------------------------------------------------------------------------------------------------
+# Body layout.  The reference feeds (B, C, T) tensors through nn.Conv1d.  On ROCm that goes to
+# MIOpen, whose fp32 Conv1d *backward* for these shapes picks a Winograd kernel at ~9 ms per call
+# (173 of a 200 ms training step, rocprofv3 trace in profiles/).  Every convolution of the scorer is
+# a GEMM over channels (k = 1) or over (tap, channel) (k = 3), so the body below keeps activations
+# as (C, B, T) -- channels outermost -- and runs all of them as plain 2-D matmuls W @ X[C, B*T]
+# (rocBLAS fp32 MFMA, forward and backward), with no layout copies between layers.  The nn.Conv1d /
+# nn.BatchNorm1d children remain the parameter holders (reference state-dict keys); their own
+# forward is not used.
+# ------------------------------------------------------------------------------------------------
+def _pointwise(conv: nn.Conv1d, x: torch.Tensor) -> torch.Tensor:
+    """1x1 Conv1d on a (C, B, T) tensor."""
+    c, b, t = x.shape
+    y = torch.matmul(conv.weight[:, :, 0], x.reshape(c, b * t))
+    if conv.bias is not None:
+        y = y + conv.bias[:, None]
+    return y.view(-1, b, t)
+
+
+def _conv_k(conv: nn.Conv1d, x: torch.Tensor) -> torch.Tensor:
+    """Conv1d with odd kernel k, padding k//2, stride 1 on a (C, B, T) tensor: GEMM over (tap, channel)."""
+    o, c, k = conv.weight.shape
+    if k == 1:
+        return _pointwise(conv, x)
+    _, b, t = x.shape
+    xp = F.pad(x, (k // 2, k // 2))
+    xu = torch.cat([xp[:, :, j : j + t] for j in range(k)], dim=0)  # ((tap, c), B, T)
+    w2 = conv.weight.permute(0, 2, 1).reshape(o, k * c)
+    y = torch.matmul(w2, xu.reshape(k * c, b * t))
+    if conv.bias is not None:
+        y = y + conv.bias[:, None]
+    return y.view(o, b, t)
+
+
 class MGFNLayerNorm(nn.Module):
     """Channel-dim norm dividing by (std + eps) -- not sqrt(var + eps) (modeling_mgfn.py:43-46)."""
 
@@ -70,9 +104,9 @@ class MGFNLayerNorm(nn.Module):
         self.g = nn.Parameter(torch.ones(1, dim, 1))
         self.b = nn.Parameter(torch.zeros(1, dim, 1))
 
-    def forward(self, x):
-        var, mean = torch.var_mean(x, dim=1, unbiased=False, keepdim=True)
-        return (x - mean) / (var.sqrt() + self.eps) * self.g + self.b
+    def forward(self, x):  # x: (C, B, T)
+        var, mean = torch.var_mean(x, dim=0, unbiased=False, keepdim=True)
+        return (x - mean) / (var.sqrt() + self.eps) * self.g.view(-1, 1, 1) + self.b.view(-1, 1, 1)
 
 
 class MGFNFeedForward(nn.Module):
@@ -85,11 +119,12 @@ class MGFNFeedForward(nn.Module):
         self.out_conv = nn.Conv1d(dim * repe, dim, 1)
 
     def forward(self, x):
-        return self.out_conv(self.dropout(self.gelu(self.in_conv(self.layer_norm(x)))))
+        return _pointwise(self.out_conv, self.dropout(self.gelu(_pointwise(self.in_conv, self.layer_norm(x)))))
 
 
 class MGFNFeatureAmplifier(nn.Module):
-    """tokens = Conv1d_k3(features) + mag_ratio * Conv1d_k3(magnitude) (modeling_mgfn.py:81-93)."""
+    """tokens = Conv1d_k3(features) + mag_ratio * Conv1d_k3(magnitude) (modeling_mgfn.py:81-93).
+    Input (bs, ncrops, T, channels+1); output (dims[0], bs*ncrops, T)."""
 
     def __init__(self, config):
         super().__init__()
@@ -100,8 +135,8 @@ class MGFNFeatureAmplifier(nn.Module):
 
     def forward(self, x):
         bs, ncrops, t, c = x.shape
-        x = x.reshape(bs * ncrops, t, c).transpose(1, 2)
-        return self.to_tokens(x[:, : self.channels]) + self.mag_ratio * self.to_mag(x[:, self.channels :])
+        x = x.reshape(bs * ncrops, t, c).permute(2, 0, 1)  # (C+1, B, T) view
+        return _conv_k(self.to_tokens, x[: self.channels]) + self.mag_ratio * _conv_k(self.to_mag, x[self.channels :])
 
 
 class GlanceAttention(nn.Module):
@@ -115,12 +150,13 @@ class GlanceAttention(nn.Module):
         self.to_qkv = nn.Conv1d(dim, dim_head * heads * 3, 1, bias=False)
         self.to_out = nn.Conv1d(dim_head * heads, dim, 1)
 
-    def forward(self, x):
-        b, _, n = x.shape
-        q, k, v = self.to_qkv(self.norm(x)).view(b, 3, self.heads, self.dim_head, n).unbind(1)
+    def forward(self, x):  # (C, B, T)
+        _, b, n = x.shape
+        qkv = _pointwise(self.to_qkv, self.norm(x)).view(3, self.heads, self.dim_head, b, n)
+        q, k, v = (t.permute(2, 0, 1, 3) for t in qkv.unbind(0))  # (b, h, d, n)
         sim = torch.matmul((q * self.scale).transpose(-1, -2), k)  # (b, h, i, j)
         out = torch.matmul(v, sim.softmax(dim=-1).transpose(-1, -2))  # (b, h, d, i)
-        return self.to_out(out.reshape(b, self.heads * self.dim_head, n))
+        return _pointwise(self.to_out, out.permute(1, 2, 0, 3).reshape(self.heads * self.dim_head, b, n))
 
 
 class FocusAttention(nn.Module):
@@ -135,18 +171,40 @@ class FocusAttention(nn.Module):
         self.rel_pos = nn.Conv1d(heads, heads, local_aggr_kernel, padding=local_aggr_kernel // 2, groups=heads)
         self.to_out = nn.Conv1d(inner, dim, 1)
 
-    def forward(self, x):
-        b, _, n = x.shape
-        v = self.to_v(self.norm(x))
-        inner = v.shape[1]
-        # channel = c_idx*heads + h_idx  ("b (c h) n -> (b c) h n")
-        out = self.rel_pos(v.reshape(b * (inner // self.heads), self.heads, n))
-        return self.to_out(out.reshape(b, inner, n))
+    def _batch_norm(self, x):  # nn.BatchNorm1d semantics on a (C, B, T) tensor
+        bn = self.norm
+        if bn.training:
+            var, mean = torch.var_mean(x, dim=(1, 2), unbiased=False)
+            if bn.track_running_stats:
+                with torch.no_grad():
+                    n = x.shape[1] * x.shape[2]
+                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                    bn.running_mean.mul_(1 - mom).add_(mean.detach(), alpha=mom)
+                    bn.running_var.mul_(1 - mom).add_(var.detach() * (n / max(n - 1, 1)), alpha=mom)
+                    bn.num_batches_tracked += 1
+        else:
+            mean, var = bn.running_mean, bn.running_var
+        scale = bn.weight * torch.rsqrt(var + bn.eps)
+        return x * scale[:, None, None] + (bn.bias - mean * scale)[:, None, None]
+
+    def forward(self, x):  # (C, B, T)
+        _, b, n = x.shape
+        v = _pointwise(self.to_v, self._batch_norm(x))
+        inner = v.shape[0]
+        h = self.heads
+        v = v.view(inner // h, h, b, n)  # channel = c_idx*heads + h_idx  ("b (c h) n -> (b c) h n")
+        k = self.rel_pos.weight.shape[-1]
+        vp = F.pad(v, (k // 2, k // 2))
+        w = self.rel_pos.weight[:, 0]  # (h, k): one temporal filter per head
+        out = self.rel_pos.bias.view(1, h, 1, 1)
+        for j in range(k):
+            out = out + w[:, j].view(1, h, 1, 1) * vp[..., j : j + n]
+        return _pointwise(self.to_out, out.reshape(inner, b, n))
 
 
 class _Block(nn.Module):
     def forward(self, x):
-        x = self.scc(x) + x
+        x = _conv_k(self.scc, x) + x
         x = self.attention(x) + x
         return self.ffn(x) + x
 
@@ -174,7 +232,7 @@ class MGFNIntermediate(nn.Module):
         self.conv = nn.Conv1d(in_dim, out_dim, 1, stride=1)
 
     def forward(self, x):
-        return self.conv(self.layer_norm(x))
+        return _pointwise(self.conv, self.layer_norm(x))
 
 
 if _PreTrainedModel is not None:
@@ -219,7 +277,8 @@ class MGFNModel(MGFNPreTrainedModel):
         self.layers = nn.Sequential(*stages)
 
     def forward(self, x: torch.Tensor) -> MGFNModelOutput:
-        return MGFNModelOutput(outputs=self.layers(self.amplifier(x)))
+        # internal layout (C, B, T); `outputs` is returned in the reference's (B, C, T) shape (a view)
+        return MGFNModelOutput(outputs=self.layers(self.amplifier(x)).permute(1, 0, 2))
 
 
 class MGFNForVideoAnomalyDetection(MGFNPreTrainedModel):
