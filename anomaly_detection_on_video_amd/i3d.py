@@ -167,6 +167,8 @@ class I3Res50(nn.Module):
         if not x.is_cuda:
             raise _lib.HipExtensionError("input is not on the GPU; there is no CPU fallback")
         self.prepare()
+        if x.shape[0] == 0:  # empty batch: nothing to launch (torch semantics: empty output)
+            return torch.empty((0, 2048, 1, 1, 1), device=x.device, dtype=torch.float32)
         with torch.no_grad():
             x = x.detach().contiguous()
 

@@ -244,6 +244,17 @@ def test_fullnet_batch_independence_and_determinism(model):
     assert torch.isfinite(y_all).all()
 
 
+def test_empty_and_ragged_batches(model):
+    """Edge cases of the driver loop: an empty batch, and a ragged last batch (fewer clips than the
+    tuned batch size) -- extract_features' DataLoader yields both kinds."""
+    y = model(torch.empty((0, 3, 16, 224, 224), device=_dev()))
+    assert y.shape == (0, 2048, 1, 1, 1)
+    x = synth_input((3, 3, 16, 112, 112), 11).to(_dev())
+    y3 = model(x).reshape(3, 2048)
+    y1 = torch.cat([model(x[i : i + 1].contiguous()).reshape(1, 2048) for i in range(3)])
+    assert rel_err(y3.cpu(), y1.cpu()) < 1e-5
+
+
 def test_product_path_refuses_cpu_and_train_mode():
     from anomaly_detection_on_video_amd import _lib
     from anomaly_detection_on_video_amd.i3d import I3Res50

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 run of bench.py into profiles/: per-kernel table of the advhip kernels,
+conv-stack time per forward from the kernel trace (to compare with bench.py's HIP-event figure),
+and optionally FETCH_SIZE / WRITE_SIZE PMC passes.
+
+    python tools/summarize_prof.py --trace gpurun_out/prof_x/runc --bench gpurun_out/prof_x.log \
+        [--fetch DIR --write DIR] --out profiles/r01_final
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+
+
+def load(pattern):
+    f = glob.glob(pattern)
+    return list(csv.DictReader(open(f[0]))) if f else []
+
+
+def family(name):
+    if "conv3d_igemm" in name or "splitk_reduce" in name:
+        return "conv"
+    if "maxpool" in name or "avgpool" in name:
+        return "pool"
+    if "advhip::" in name:
+        return "advhip-other"
+    return "other"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trace", required=True)
+    ap.add_argument("--bench", default="")
+    ap.add_argument("--fetch", default="")
+    ap.add_argument("--write", default="")
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    rows = load(os.path.join(a.trace, "*_kernel_trace.csv"))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    dur = lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    # forwards = stem conv ... global_avgpool
+    ends = [i for i, r in enumerate(rows) if "global_avgpool" in r["Kernel_Name"]]
+    fwd = []
+    prev = -1
+    for e in ends:
+        seg = [r for r in rows[prev + 1 : e + 1] if family(r["Kernel_Name"]) in ("conv", "pool")]
+        prev = e
+        if not seg:
+            continue
+        conv = sum(dur(r) for r in seg if family(r["Kernel_Name"]) == "conv")
+        pool = sum(dur(r) for r in seg if family(r["Kernel_Name"]) == "pool")
+        span = int(seg[-1]["End_Timestamp"]) - int(seg[0]["Start_Timestamp"])
+        fwd.append((conv / 1e6, pool / 1e6, span / 1e6, sum(1 for r in seg if family(r["Kernel_Name"]) == "conv")))
+    per = collections.OrderedDict()
+    for r in rows:
+        if "advhip::" not in r["Kernel_Name"]:
+            continue
+        n = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        d = per.setdefault(n, [0, 0])
+        d[0] += 1
+        d[1] += dur(r)
+    bench = None
+    if a.bench and os.path.exists(a.bench):
+        for line in open(a.bench):
+            if line.startswith('{"metric"'):
+                bench = json.loads(line)
+    out = ["# rocprofv3 summary of `bench.py` (%s)\n" % os.path.basename(a.out)]
+    if bench:
+        out.append("bench line under the profiler: value %.1f clips/s, %.3f ms/step, conv stack (HIP events) %.3f ms -> %.1f TFLOP/s\n"
+                   % (bench["value"], bench["ms_per_step"], bench["roofline"]["avg_ms_per_launch_set"], bench["roofline"]["achieved"]))
+    timed = fwd[-(bench["steps"] if bench else len(fwd)):]
+    if timed:
+        c = sum(f[0] for f in timed) / len(timed)
+        out.append("kernel trace, timed forwards (%d): conv kernels %.3f ms per forward (%d launches incl. split-K reduces), pools %.3f ms, "
+                   "first-to-last span %.3f ms\n" % (len(timed), c, timed[-1][3], sum(f[1] for f in timed) / len(timed), sum(f[2] for f in timed) / len(timed)))
+        if bench:
+            out.append("agreement trace vs HIP events: %.1f %%\n" % (100 * c / bench["roofline"]["avg_ms_per_launch_set"]))
+    out.append("\n| kernel | calls | total ms | avg us |\n|---|---:|---:|---:|\n")
+    for n, (calls, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+        out.append("| `%s` | %d | %.2f | %.1f |\n" % (n, calls, t / 1e6, t / calls / 1e3))
+    if a.fetch and a.write:
+        tot = {}
+        for kind, d in (("FETCH_SIZE", a.fetch), ("WRITE_SIZE", a.write)):
+            agg = collections.defaultdict(float)
+            cnt = collections.defaultdict(int)
+            for r in load(os.path.join(d, "*_counter_collection.csv")):
+                fam = family(r["Kernel_Name"])
+                agg[fam] += float(r["Counter_Value"])
+                cnt[fam] += 1
+            tot[kind] = (agg, cnt)
+        nf = len([1 for r in load(os.path.join(a.fetch, "*_counter_collection.csv")) if "global_avgpool" in r["Kernel_Name"]])
+        out.append("\n## HBM traffic (PMC, separate passes, %d forwards each)\n\n" % nf)
+        out.append("| family | FETCH_SIZE KB/forward | x2 (gfx950 fetch correction) GB | WRITE_SIZE KB/forward | GB |\n|---|---:|---:|---:|---:|\n")
+        res = {}
+        for fam in ("conv", "pool"):
+            f = tot["FETCH_SIZE"][0][fam] / max(nf, 1)
+            w = tot["WRITE_SIZE"][0][fam] / max(nf, 1)
+            out.append("| %s | %.0f | %.2f | %.0f | %.2f |\n" % (fam, f, 2 * f * 1024 / 1e9, w, w * 1024 / 1e9))
+            res[fam] = {"fetch_kb": f, "write_kb": w, "bytes_corrected": 2 * f * 1024 + w * 1024}
+        with open(a.out + "_traffic.json", "w") as fp:
+            json.dump(res, fp, indent=1)
+    with open(a.out + "_summary.md", "w") as fp:
+        fp.writelines(out)
+    print("".join(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -68,12 +68,12 @@ def main():
             kpad = pc.w_packed.shape[0]
             cands = []
             taps = pc.kernel[0] * pc.kernel[1] * pc.kernel[2]
-            for algo in ((3,) if args.quick else _lib.IGEMM_ALGOS) + _lib.FAST_ALGOS + _lib.DMA_ALGOS:
+            for algo in ((3,) if args.quick else _lib.IGEMM_ALGOS) + ((35,) if args.quick else _lib.FAST_ALGOS) + _lib.DMA_ALGOS:
                 bm, bn, bk = _lib.algo_tile(algo)
                 if pc.cout % bn:
                     continue
                 tiles = -(-(y.numel() // pc.cout) // bm) * (pc.cout // bn)
-                for sp in (1, 2, 3, 4, 6, 8, 12, 16):
+                for sp in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16):
                     if sp > 1 and (tiles * sp > 4096 or kpad // bk < 2 * sp):
                         continue
                     cands.append((algo, sp))
