@@ -35,6 +35,19 @@ def metric_name() -> str:
         return "16-frame 224² RGB clips/sec (I3D extract→MIL score), 1/2/4/8 GPU + %MFMA-peak"
 
 
+def measured_traffic(batch: int):
+    """HBM bytes per launch set from the committed PMC passes of this same command
+    (`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, separate passes; FETCH_SIZE doubled per the
+    gfx950 correction; profiles/r01_final_summary.md).  Counters cannot be read from inside the
+    process, so this is the profiled value for the benchmarked batch, else null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_final_traffic.json")) as f:
+            t = json.load(f)
+        return float(t["conv"]["bytes_corrected"]) if batch == 32 else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(budget_s: float = 12.0):
     """The oracle (CPU restatement of the reference's path, pinned by tests/golden) timed on this
     host's cores on a bounded sample: config 1 of BASELINE.json (8 crop-clips per I3D forward) plus
@@ -200,7 +213,8 @@ def main():
             },
             "roofline": {
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(args.batch),
+                "traffic_unit": "bytes per launch set (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes in profiles/)",
                 "kernel": "conv3d fp32-MFMA stack (53 launches per step on rank 0)",
                 "flop_per_launch_set": args.batch * GFLOP_PER_CLIP * 1e9, "avg_ms_per_launch_set": round(conv_ms_avg, 4),
             },
