@@ -80,6 +80,7 @@ SIGNATURES = {
     "advhip_mgfn_loss_bwd_f32": (C.c_int, [_P] * 14 + [_I] * 5 + [_P]),
     "advhip_segment_features_f32": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "advhip_add_magnitude_f32": (C.c_int, [_P, _P, _L, _I, _P]),
+    "advhip_normalize_permute_u8": (C.c_int, [_P, _P, _L, _I, _I, _I, _I, C.c_float, C.c_float, _P]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -127,7 +128,7 @@ def require_gpu(*tensors: torch.Tensor) -> None:
                 "this op runs only as a HIP kernel on an AMD GPU; got a tensor on "
                 f"'{t.device}'. Move the module and its inputs to cuda (there is no CPU fallback)."
             )
-        if t.dtype != torch.float32 and t.dtype != torch.int64 and t.dtype != torch.int32:
+        if t.dtype not in (torch.float32, torch.int64, torch.int32, torch.uint8):
             raise HipExtensionError(f"unsupported dtype {t.dtype}; the kernels compute in fp32")
         if not t.is_contiguous():
             raise HipExtensionError("HIP kernels need contiguous tensors")

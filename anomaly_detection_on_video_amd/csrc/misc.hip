@@ -54,9 +54,46 @@ __global__ void add_magnitude_kernel(const float* __restrict__ f, float* __restr
   if (lane == 0) q[C] = sqrtf(s);
 }
 
+// uint8 frames (N, T, C, H, W) -> fp32 (N, C, T, H, W), y = (x - mean) / std: the reference's
+// PILToTensor().float() + GroupNormalize + the (B,10,16,3,H,W)->(B,10,3,16,H,W) permute
+// (/root/reference/src/dataset.py:175-183, extract_features.py:83) in one pass, so only uint8 crosses
+// PCIe.  Each thread converts 4 consecutive pixels of a row (one 32-bit load, one 16-byte store).
+__global__ void normalize_permute_u8_kernel(const uint8_t* __restrict__ x, float* __restrict__ y, int T, int C,
+                                            long long HW, float mean, float stdv, long long total4) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long hw4 = HW / 4;
+    const long long p4 = i % hw4;            // output order: (n, c, t, hw)
+    long long r = i / hw4;
+    const int t = (int)(r % T);
+    r /= T;
+    const int c = (int)(r % C);
+    const long long n = r / C;
+    const uint32_t v = *reinterpret_cast<const uint32_t*>(x + (((n * T + t) * C + c) * HW + p4 * 4));
+    float4 o;
+    o.x = ((float)(v & 0xff) - mean) / stdv;
+    o.y = ((float)((v >> 8) & 0xff) - mean) / stdv;
+    o.z = ((float)((v >> 16) & 0xff) - mean) / stdv;
+    o.w = ((float)(v >> 24) - mean) / stdv;
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
+}
+
 }  // namespace advhip
 
 using namespace advhip;
+
+extern "C" int advhip_normalize_permute_u8(const uint8_t* x, float* y, int64_t N, int32_t T, int32_t C, int32_t H,
+                                           int32_t W, float mean, float stdv, void* stream) {
+  ADVHIP_REQUIRE(x && y && N > 0 && T > 0 && C > 0 && H > 0 && W > 0, "normalize_permute_u8: bad arguments");
+  ADVHIP_REQUIRE(((long long)H * W) % 4 == 0, "normalize_permute_u8: H*W=%lld must be a multiple of 4", (long long)H * W);
+  ADVHIP_REQUIRE(stdv != 0.f, "normalize_permute_u8: std must be non-zero");
+  const long long total4 = (long long)N * T * C * H * W / 4;
+  const int grid = (int)std::min<long long>((total4 + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(normalize_permute_u8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, T, C,
+                     (long long)H * W, mean, stdv, total4);
+  return check_launch("normalize_permute_u8");
+}
 
 extern "C" int advhip_segment_features_f32(const float* feats, float* out, int32_t n_clips, int32_t ncrops, int32_t C,
                                            int32_t seg, void* stream) {

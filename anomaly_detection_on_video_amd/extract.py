@@ -49,8 +49,13 @@ def extract_clip_batch(model, clips: torch.Tensor, max_crop_clips: int = 40, sha
         raise ValueError(f"expected (B, ncrops, T, 3, H, W), got {tuple(clips.shape)}")
     B, ncrops = clips.shape[:2]
     dev = next(model.parameters()).device
-    # (B, ncrops, T, C, H, W) -> (B*ncrops, C, T, H, W): the reference's permute (:83) + crop fold
-    folded = clips.to(dev, non_blocking=True).permute(0, 1, 3, 2, 4, 5).reshape(B * ncrops, clips.shape[3], clips.shape[2], *clips.shape[4:])
+    if clips.dtype == torch.uint8:
+        # raw TenCrop'd pixels: only uint8 crosses PCIe; float conversion, (x-114.75)/57.375 and the
+        # (T,C)->(C,T) permute happen in one HIP pass (dataset.py:175-183 + extract_features.py:83)
+        folded = mil_ops.normalize_permute_u8(clips.to(dev, non_blocking=True).reshape(B * ncrops, *clips.shape[2:]))
+    else:
+        # (B, ncrops, T, C, H, W) -> (B*ncrops, C, T, H, W): the reference's permute (:83) + crop fold
+        folded = clips.to(dev, non_blocking=True).permute(0, 1, 3, 2, 4, 5).reshape(B * ncrops, clips.shape[3], clips.shape[2], *clips.shape[4:])
 
     def run(units: torch.Tensor) -> torch.Tensor:
         outs = []

@@ -10,6 +10,7 @@ CUDA tensors only; no fallback.  Reference semantics: modeling_mgfn.py:302-374, 
 """
 from __future__ import annotations
 
+from ctypes import c_float as C_float
 from typing import Optional, Tuple
 
 import torch
@@ -165,4 +166,20 @@ def add_magnitude(feats: torch.Tensor) -> torch.Tensor:
     rows = feats.numel() // C
     out = torch.empty(feats.shape[:-1] + (C + 1,), device=feats.device, dtype=torch.float32)
     check(_lib.load().advhip_add_magnitude_f32(ptr(feats), ptr(out), rows, C, stream()), "add_magnitude")
+    return out
+
+
+PIXEL_MEAN, PIXEL_STD = 114.75, 57.375  # GroupNormalize constants, src/dataset.py:180-181
+
+
+def normalize_permute_u8(frames: torch.Tensor, mean: float = PIXEL_MEAN, std: float = PIXEL_STD) -> torch.Tensor:
+    """uint8 (N, T, C, H, W) -> fp32 (N, C, T, H, W), (x - mean) / std, one HIP pass."""
+    frames = frames.contiguous()
+    require_gpu(frames)
+    if frames.dtype != torch.uint8 or frames.dim() != 5:
+        raise ValueError(f"expected uint8 (N,T,C,H,W), got {frames.dtype} {tuple(frames.shape)}")
+    n, t, c, h, w = frames.shape
+    out = torch.empty((n, c, t, h, w), device=frames.device, dtype=torch.float32)
+    check(_lib.load().advhip_normalize_permute_u8(ptr(frames), ptr(out), n, t, c, h, w, C_float(mean), C_float(std), stream()),
+          "normalize_permute_u8")
     return out

@@ -171,6 +171,13 @@ int advhip_segment_features_f32(const float* feats, float* out, int32_t n_clips,
  * = L2 norm of the row. */
 int advhip_add_magnitude_f32(const float* feats, float* out, int64_t rows, int32_t C, void* stream);
 
+/* Clip pre-processing on the device: uint8 frames (N, T, C, H, W) -> fp32 (N, C, T, H, W) with
+ * y = (x - mean) / std.  Replaces PILToTensor().float() + GroupNormalize(114.75, 57.375)
+ * (src/dataset.py:175-183) and the permute of extract_features.py:83, so that only uint8 pixels
+ * cross PCIe.  H*W must be a multiple of 4. */
+int advhip_normalize_permute_u8(const uint8_t* x, float* y, int64_t N, int32_t T, int32_t C,
+                                int32_t H, int32_t W, float mean, float stdv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

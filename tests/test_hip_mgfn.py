@@ -218,6 +218,21 @@ def test_add_magnitude_on_device():
     assert rel_err(out, g["addmag"]) < 1e-6
 
 
+def test_normalize_permute_u8_bit_exact():
+    """uint8 clip pre-processing == PILToTensor().float() -> (x-114.75)/57.375 -> permute, bit for bit."""
+    from anomaly_detection_on_video_amd import mil_ops
+
+    g = torch.Generator().manual_seed(3)
+    for shape in ((3, 16, 3, 32, 36), (1, 2, 1, 2, 2), (2, 5, 3, 7, 12)):
+        x = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
+        ref = ((x.float() - 114.75) / 57.375).permute(0, 2, 1, 3, 4).contiguous()
+        out = mil_ops.normalize_permute_u8(x.to(DEV)).cpu()
+        assert out.shape == ref.shape and torch.equal(out, ref)
+    from anomaly_detection_on_video_amd import _lib
+    with pytest.raises(_lib.HipExtensionError):
+        mil_ops.normalize_permute_u8(torch.zeros((1, 1, 1, 3, 3), dtype=torch.uint8, device=DEV))  # H*W % 4 != 0
+
+
 def test_head_refuses_cpu_tensors():
     from anomaly_detection_on_video_amd import _lib
     from anomaly_detection_on_video_amd.models.mgfn import MGFNConfig, MGFNForVideoAnomalyDetection

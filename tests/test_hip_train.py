@@ -107,6 +107,12 @@ def test_extract_driver_layout_resume_and_segment(tmp_path):
     ref = host_oracle.stack_crop_outputs(per_batch)
     assert rel_err(feats, ref) < TOL
 
+    # uint8 source: pixels in, same features as normalising on the host first
+    pix = torch.randint(0, 256, (2, 10, 16, 3, 64, 64), generator=torch.Generator().manual_seed(5), dtype=torch.uint8)
+    f_u8 = extract.extract_video(model, pix, batch_size=2, max_crop_clips=8)
+    f_f32 = extract.extract_video(model, (pix.float() - 114.75) / 57.375, batch_size=2, max_crop_clips=8)
+    np.testing.assert_array_equal(f_u8, f_f32)
+
     out = str(tmp_path / "feats")
     calls = []
 
