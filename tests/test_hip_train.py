@@ -161,3 +161,84 @@ def test_stream_scores_match_oracle_end_to_end():
         video = torch.from_numpy(host_oracle.add_magnitude(f)).unsqueeze(0).permute(0, 2, 1, 3)
         ref = mgfn_oracle.mgfn_forward(video, msd).scores.reshape(-1)
         assert rel_err(s.cpu(), ref) < TOL
+
+
+def test_end_to_end_extract_segment_train_auc(tmp_path):
+    """BASELINE config 5 in miniature: synthetic uint8 videos -> I3D extract (HIP) -> segment(32) for
+    train / raw for test + make_gt rule -> MGFN training through run.py -> frame-level AUC; the AUC of
+    the trained weights is then recomputed with the CPU oracle from the same features."""
+    import io
+    import json
+    import zipfile
+
+    import run
+    from anomaly_detection_on_video_amd import extract, metrics
+    from anomaly_detection_on_video_amd.dataset import build_feature_dataset
+    from anomaly_detection_on_video_amd.gt import frame_ground_truth
+    from anomaly_detection_on_video_amd.i3d import I3Res50
+    from oracle import host_oracle, mgfn_oracle
+
+    torch.manual_seed(0)
+    bb = I3Res50()
+    bb.load_state_dict(synth_i3d_state_dict())
+    bb = bb.eval().to(DEV)
+    g = torch.Generator().manual_seed(11)
+
+    def video(n_clips, burst=None):
+        v = torch.randint(60, 140, (n_clips, 10, 16, 3, 32, 32), generator=g, dtype=torch.uint8)
+        if burst is not None:  # "anomalous" clips: saturated frames -> different feature statistics
+            v[burst[0] : burst[1]] = torch.randint(200, 256, v[burst[0] : burst[1]].shape, generator=g, dtype=torch.uint8)
+        return v
+
+    root = tmp_path / "corpus"
+    os.makedirs(root)
+
+    def put(z, name, arr):
+        buf = io.BytesIO()
+        np.save(buf, arr.astype(np.float32))
+        z.writestr(name, buf.getvalue())
+
+    with zipfile.ZipFile(root / "train.zip", "w") as z:
+        for i in range(4):
+            f = extract.extract_video(bb, video(5), batch_size=5, max_crop_clips=50)
+            put(z, f"train/Normal_Videos{i:03d}_x264_i3d.npy", host_oracle.segment_features(f, 32))
+        for i in range(4):
+            f = extract.extract_video(bb, video(6, burst=(2, 4)), batch_size=6, max_crop_clips=60)
+            put(z, f"train/Abuse{i:03d}_x264_i3d.npy", extract.segment_array(f, 32))
+    gt, test_feats = {}, {}
+    with zipfile.ZipFile(root / "test.zip", "w") as z:
+        for i in range(4):
+            n = 5 + i
+            if i % 2:
+                f = extract.extract_video(bb, video(n, burst=(1, 3)), batch_size=8, max_crop_clips=40)
+                name, ev = f"Burglary{i:03d}_x264", ((16, 47), (-1, -1))
+            else:
+                f = extract.extract_video(bb, video(n), batch_size=8, max_crop_clips=40)
+                name, ev = f"Normal_Videos_{900 + i}_x264", ((-1, -1), (-1, -1))
+            put(z, f"test/{name}_i3d.npy", f)
+            gt[name] = frame_ground_truth(n, *ev)
+            test_feats[name] = f
+    with open(root / "ground_truth.json", "w") as f:
+        json.dump(gt, f)
+
+    trainer = run.main([
+        "data=synthetic", f"data.local_path={root}", "data.batch_size=2", "trainer.cls.max_epochs=3",
+        f"trainer.callbacks.model_checkpoint.dirpath={tmp_path / 'ckpt'}", "trainer.callbacks.model_checkpoint.every_n_epochs=1",
+        f"trainer.logger.jsonl.path={tmp_path / 'log.jsonl'}",
+    ])
+    vals = [h for h in trainer.history if "valid/rec_auc" in h]
+    assert len(vals) == 3
+    gpu_auc = vals[-1]["valid/rec_auc"]
+    # oracle recomputation from the trained weights
+    state = torch.load(tmp_path / "ckpt" / "last.pt", map_location="cpu")["model"]
+    ds = build_feature_dataset("test", local_path=str(root), filename="test.zip", dynamic_load=False)
+    preds, labels = [], []
+    for i in range(len(ds)):
+        item = ds[i]
+        video_t = torch.from_numpy(item["feature"]).unsqueeze(0).permute(0, 2, 1, 3)
+        with torch.no_grad():
+            preds.append(mgfn_oracle.mgfn_forward(video_t.float(), state).scores.reshape(-1).numpy())
+        labels.append(item["label"])
+    cpu_auc, _ = metrics.frame_level_auc(preds, labels, 16)
+    assert abs(cpu_auc - gpu_auc) < 2e-3, (cpu_auc, gpu_auc)
+    assert 0.0 <= gpu_auc <= 1.0
