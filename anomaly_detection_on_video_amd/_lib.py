@@ -25,7 +25,6 @@ ALGO_IGEMM_128x128x32 = 5
 ALGO_IGEMM_128x64x32 = 6
 ALGO_IGEMM_64x64x32 = 7
 ALGO_IGEMM_64x128x32 = 8
-ALGO_STEM = 16
 ALGO_FAST_BASE = 32  # + tile id: scalar-offset / tap-mask gather (<= 32 taps)
 IGEMM_ALGOS = (1, 2, 3, 4, 5, 6, 7, 8)
 FAST_ALGOS = tuple(ALGO_FAST_BASE + a for a in IGEMM_ALGOS)

@@ -879,9 +879,6 @@ extern "C" int advhip_bn_fold_f32(const float* gamma, const float* beta, const f
 }
 
 namespace advhip {
-int launch_stem(const advhip_conv3d_desc* d, const float* x, const float* w_packed, const float* scale,
-                const float* shift, float* y, hipStream_t stream);  // conv_stem.hip
-
 struct Choice {
   int algo;    // ADVHIP_ALGO_IGEMM_*
   int splits;  // >= 1
@@ -950,7 +947,6 @@ static Geometry geometry(const advhip_conv3d_desc* d) {
 
 extern "C" int64_t advhip_conv3d_workspace_bytes(const advhip_conv3d_desc* d) {
   if (validate(d)) return -1;
-  if (d->algo == ADVHIP_ALGO_STEM) return 0;
   const Geometry g = geometry(d);
   const Choice c = choose(d, g.M, g.Kpad);
   return c.splits > 1 ? (int64_t)c.splits * g.M * d->Cout * (int64_t)sizeof(float) : 0;
@@ -982,10 +978,6 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
   a.relu = d->relu;
   a.vw = (a.THWo % 4 == 0) ? 4 : (a.THWo % 2 == 0 ? 2 : 1);
 
-  if (d->algo == ADVHIP_ALGO_STEM) {
-    ADVHIP_REQUIRE(residual == nullptr, "conv3d: stem kernel takes no residual");
-    return launch_stem(d, x, w_packed, scale, shift, y, (hipStream_t)stream);
-  }
   const Choice c = choose(d, M, g.Kpad);
   int BM, BN, BK;
   tile_of(c.algo, &BM, &BN, &BK);

@@ -46,7 +46,6 @@ extern "C" {
 #define ADVHIP_ALGO_FAST_BASE 32
 /* + tile id: the fast gather with LDS-DMA operand staging into a 3-deep ring (no 128x128x32) */
 #define ADVHIP_ALGO_DMA_BASE 64
-#define ADVHIP_ALGO_STEM 16 /* dedicated Cin=3 k(5,7,7) s2 kernel, LDS halo tile */
 
 typedef struct advhip_conv3d_desc {
   int32_t B, Cin, T, H, W;    /* input  (B, Cin, T, H, W) */
