@@ -19,6 +19,7 @@
 // Replaces nn.Conv3d + nn.BatchNorm3d(eval) + residual add + nn.ReLU of
 // /root/reference/src/i3d.py:98-121, 262-272, 303-305.
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -906,15 +907,11 @@ static Choice choose(const advhip_conv3d_desc* d, long long M, int Kpad) {
   Choice c{d->algo, d->splits};
   const int N = d->Cout;
   if (c.algo == ADVHIP_ALGO_AUTO) {
-    const long long t128 = (M + 127) / 128, t64 = (M + 63) / 64;
-    const bool n128 = N % 128 == 0;
-    if (n128 && t128 * (N / 128) >= 1024) c.algo = ADVHIP_ALGO_IGEMM_128x128;
-    else if (t128 * (N / 64) >= 1024) c.algo = ADVHIP_ALGO_IGEMM_128x64;
-    else if (n128 && t64 * (N / 128) >= 768) c.algo = ADVHIP_ALGO_IGEMM_64x128;
-    else if (t64 * (N / 64) >= 768) c.algo = ADVHIP_ALGO_IGEMM_64x64;
-    else c.algo = n128 ? ADVHIP_ALGO_IGEMM_64x128 : ADVHIP_ALGO_IGEMM_64x64;  // + split-K below
+    // what the measured table (tuned/gfx950.json) picks almost everywhere: 64x64x16 tiles -- many
+    // small workgroups (6 per CU) hide each other's prologue/epilogue -- on the LDS-DMA kernel
     const long long in_elems = (long long)d->B * d->Cin * d->T * d->H * d->W;
-    if (fast_ok(d, in_elems, (long long)Kpad * N)) c.algo += ADVHIP_ALGO_FAST_BASE;
+    c.algo = ADVHIP_ALGO_IGEMM_64x64;
+    if (fast_ok(d, in_elems, (long long)Kpad * N)) c.algo += ADVHIP_ALGO_DMA_BASE;
   }
   if (c.splits <= 0) {
     int BM, BN, BK;
@@ -922,7 +919,7 @@ static Choice choose(const advhip_conv3d_desc* d, long long M, int Kpad) {
     const long long tiles = ((M + BM - 1) / BM) * (N / BN);
     const int nk = Kpad / BK;
     int s = 1;
-    while (tiles * s < 768 && s < 8 && nk / (s * 2) >= 8) s *= 2;
+    while (tiles * s < 1024 && s < 9 && nk / (s + 1) >= 8) ++s;
     c.splits = s;
   }
   return c;
@@ -991,6 +988,11 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
     a.pad_off = d->pt * d->H * d->W + d->ph * d->W + d->pw;
     a.x_bytes = (unsigned)((in_elems + a.pad_off) * 4);
     a.w_bytes = (unsigned)((long long)g.Kpad * d->Cout * 4);
+    // timing-only diagnostic (cdna_hip_programming.md section 7): zero-record descriptors make the
+    // buffer unit drop every operand load while the instruction stream, waits and barriers stay, which
+    // prices the memory side of the kernel.  Outputs are wrong by construction.
+    static const bool zero_records = getenv("ADVHIP_DEBUG_ZERO_RECORDS") != nullptr;
+    if (zero_records) a.x_bytes = a.w_bytes = 0;
   }
   ADVHIP_REQUIRE(d->Cout % BN == 0, "conv3d: Cout=%d not a multiple of the %d-wide N tile", d->Cout, BN);
   ADVHIP_REQUIRE(g.Kpad % BK == 0 || BK == 16, "conv3d: internal: Kpad");

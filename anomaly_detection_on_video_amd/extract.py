@@ -39,10 +39,11 @@ def load_feature_extraction_model(model_name: str = "tushar-n-baseline", **facto
 
 
 @torch.no_grad()
-def extract_clip_batch(model, clips: torch.Tensor, max_crop_clips: int = 40, sharded: bool = False) -> torch.Tensor:
+def extract_clip_batch(model, clips: torch.Tensor, max_crop_clips: int = 32, sharded: bool = False) -> torch.Tensor:
     """(B, ncrops, 16, 3, H, W) TenCrop'd clips -> (B, ncrops, 2048) features on the device.
 
-    `max_crop_clips` bounds the folded batch per backbone launch (activation memory).  With
+    `max_crop_clips` bounds the folded batch per backbone launch (activation memory; 32 is the batch
+    the tile table in tuned/gfx950.json was measured at).  With
     `sharded=True` the folded crop-clips are split over the ranks of the default process group
     and the rows all-gathered (dist.sharded_map_rows)."""
     if clips.dim() != 6:
