@@ -30,10 +30,14 @@ IGEMM_ALGOS = (1, 2, 3, 4, 5, 6, 7, 8)
 FAST_ALGOS = tuple(ALGO_FAST_BASE + a for a in IGEMM_ALGOS)
 ALGO_DMA_BASE = 64  # + tile id: fast gather + LDS-DMA staging into a 3-deep ring (no 128x128x32)
 DMA_ALGOS = tuple(ALGO_DMA_BASE + a for a in (1, 2, 3, 4, 6, 7, 8))
+ALGO_DMA4_BASE = 96  # + tile id 2..4: 4-deep ring
+DMA4_ALGOS = tuple(ALGO_DMA4_BASE + a for a in (2, 3, 4))
 
 
 def algo_tile(algo: int):
     """(BM, BN, BK) of an implicit-GEMM algorithm id."""
+    if algo >= ALGO_DMA4_BASE:
+        algo -= ALGO_DMA4_BASE
     if algo >= ALGO_DMA_BASE:
         algo -= ALGO_DMA_BASE
     if algo >= ALGO_FAST_BASE:

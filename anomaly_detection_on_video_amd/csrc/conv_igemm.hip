@@ -576,14 +576,15 @@ __device__ __forceinline__ void lds_wait(Frag<NA>& a, Frag<NB>& b) {
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a.v), "+v"(b.v) : "n"(CNT));
 }
 
-template <int BM, int BN, int BK, bool CHECK>
+template <int BM, int BN, int BK, bool CHECK, int NS = 3>
 __global__ __launch_bounds__(256) void conv3d_igemm_dma_kernel(const ConvArgs a) {
   using Cfg = IgemmCfg<BM, BN, BK>;
   using D = DmaCfg<BM, BN, BK>;
   constexpr int FM = Cfg::FM, FN = Cfg::FN, KR = D::KR, LA = D::LA, LB = D::LB, KS = BK / 4;
-  static_assert(LB >= 1 && LA >= 1 && LA + LB <= 31, "tile / vmcnt budget");
+  static_assert(NS == 3 || NS == 4, "ring depth");
+  static_assert(LB >= 1 && LA >= 1 && (NS - 2) * (LA + LB) <= 63, "tile / vmcnt budget");
   constexpr unsigned OOB = 0xFFFFFF00u;
-  constexpr int RING = 3 * D::STAGE;
+  constexpr int RING = NS * D::STAGE;
   constexpr int SMEM = RING > Cfg::ST_FLOATS ? RING : Cfg::ST_FLOATS;
 
   __shared__ __attribute__((aligned(16))) float smem[SMEM];
@@ -711,22 +712,25 @@ __global__ __launch_bounds__(256) void conv3d_igemm_dma_kernel(const ConvArgs a)
   const int nk_all = a.Kpad / BK;
   const int kt0 = (nk_all * split) / a.splits;
   const int kt1 = (nk_all * (split + 1)) / a.splits;
-  // prologue: two k-tiles in flight
-  if (kt0 < kt1) issue_tile(kt0 * BK, 0);
-  if (kt0 + 1 < kt1) issue_tile((kt0 + 1) * BK, 1);
+  // prologue: NS-1 k-tiles in flight
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i)
+    if (kt0 + i < kt1) issue_tile((kt0 + i) * BK, i);
   int stage = 0;
   for (int kt = kt0; kt < kt1; ++kt) {
-    // tile kt has landed once at most the next tile's LA+LB loads are still outstanding
-    if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA + LB) : "memory");
+    // tile kt has landed once only the loads of the younger tiles in flight (<= NS-2) are outstanding
+    const int younger = kt1 - 1 - kt;
+    if (NS == 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LA + LB)) : "memory");
+    else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA + LB) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");  // all waves' parts of tile kt are in LDS; stage (kt-1)%3 is free
-    if (kt + 2 < kt1) {
-      sload_entries<LA>(ktab2, ((kt + 2) * BK + kr * LA) * 8, ent);
-      compute(std::true_type{}, stage, (kt + 2) * BK, stage == 0 ? 2 : stage - 1);
+    asm volatile("s_barrier" ::: "memory");  // all waves' parts of tile kt are in LDS; stage (kt-1)%NS is free
+    if (kt + NS - 1 < kt1) {
+      sload_entries<LA>(ktab2, ((kt + NS - 1) * BK + kr * LA) * 8, ent);
+      compute(std::true_type{}, stage, (kt + NS - 1) * BK, stage == 0 ? NS - 1 : stage - 1);
     } else {
       compute(std::false_type{}, stage, 0, 0);
     }
-    stage = stage == 2 ? 0 : stage + 1;
+    stage = stage == NS - 1 ? 0 : stage + 1;
   }
   __syncthreads();  // every wave is done with the ring before the epilogue reuses it as staging
   igemm_epilogue<BM, BN, BK>(a, acc, smem, split, m0, n0, wave, lane);
@@ -886,6 +890,7 @@ struct Choice {
 };
 
 static void tile_of(int algo, int* BM, int* BN, int* BK) {
+  if (algo >= ADVHIP_ALGO_DMA4_BASE) algo -= ADVHIP_ALGO_DMA4_BASE;
   if (algo >= ADVHIP_ALGO_DMA_BASE) algo -= ADVHIP_ALGO_DMA_BASE;
   if (algo >= ADVHIP_ALGO_FAST_BASE) algo -= ADVHIP_ALGO_FAST_BASE;
   const int t = (algo - 1) & 3;
@@ -979,7 +984,9 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
   int BM, BN, BK;
   tile_of(c.algo, &BM, &BN, &BK);
   const bool fast = c.algo >= ADVHIP_ALGO_FAST_BASE;  // includes the LDS-DMA ids
-  const int base_algo = c.algo >= ADVHIP_ALGO_DMA_BASE ? c.algo - ADVHIP_ALGO_DMA_BASE : (fast ? c.algo - ADVHIP_ALGO_FAST_BASE : c.algo);
+  const int base_algo = c.algo >= ADVHIP_ALGO_DMA4_BASE ? c.algo - ADVHIP_ALGO_DMA4_BASE
+                        : c.algo >= ADVHIP_ALGO_DMA_BASE ? c.algo - ADVHIP_ALGO_DMA_BASE
+                        : (fast ? c.algo - ADVHIP_ALGO_FAST_BASE : c.algo);
   ADVHIP_REQUIRE(base_algo >= ADVHIP_ALGO_IGEMM_128x128 && base_algo <= ADVHIP_ALGO_IGEMM_64x128x32, "conv3d: unknown algo %d", c.algo);
   if (fast) {
     ADVHIP_REQUIRE(fast_ok(d, in_elems, (long long)g.Kpad * d->Cout),
@@ -1026,7 +1033,15 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
     if (nocheck) hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, false>), grid, dim3(256), 0, st, a);  \
     else hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, true>), grid, dim3(256), 0, st, a);           \
     break;
+#define ADVHIP_DMA4_CASE(ID, BM_, BN_, BK_)                                                                          \
+  case ADVHIP_ALGO_DMA4_BASE + ID:                                                                                   \
+    if (nocheck) hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, false, 4>), grid, dim3(256), 0, st, a);  \
+    else hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, true, 4>), grid, dim3(256), 0, st, a);           \
+    break;
   switch (c.algo) {
+    ADVHIP_DMA4_CASE(ADVHIP_ALGO_IGEMM_128x64, 128, 64, 16)
+    ADVHIP_DMA4_CASE(ADVHIP_ALGO_IGEMM_64x64, 64, 64, 16)
+    ADVHIP_DMA4_CASE(ADVHIP_ALGO_IGEMM_64x128, 64, 128, 16)
     ADVHIP_DMA_CASE(ADVHIP_ALGO_IGEMM_128x128, 128, 128, 16)
     ADVHIP_DMA_CASE(ADVHIP_ALGO_IGEMM_128x64, 128, 64, 16)
     ADVHIP_DMA_CASE(ADVHIP_ALGO_IGEMM_64x64, 64, 64, 16)

@@ -46,6 +46,8 @@ extern "C" {
 #define ADVHIP_ALGO_FAST_BASE 32
 /* + tile id: the fast gather with LDS-DMA operand staging into a 3-deep ring (no 128x128x32) */
 #define ADVHIP_ALGO_DMA_BASE 64
+/* + tile id 2..4: the same with a 4-deep ring (three k-tiles in flight) */
+#define ADVHIP_ALGO_DMA4_BASE 96
 
 typedef struct advhip_conv3d_desc {
   int32_t B, Cin, T, H, W;    /* input  (B, Cin, T, H, W) */

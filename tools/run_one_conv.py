@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--splits", type=int, default=0)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--res", action="store_true")
+    ap.add_argument("--relu-input", action="store_true", help="non-negative input with ~50%% exact zeros, like post-ReLU activations")
     a = ap.parse_args()
     cin, cout, kt, kh, kw, st, sh, sw, pt, ph, pw, B, T, H, W = (int(v) for v in a.key.split(","))
     dev = torch.device("cuda:0")
@@ -29,6 +30,8 @@ def main():
     ones = torch.ones(cout, device=dev)
     pc = ops.pack_conv(w, ones, ones * 0.1, ones * 0.05, ones, 1e-5, (st, sh, sw), (pt, ph, pw), name="one")
     x = torch.randn((B, cin, T, H, W), device=dev, generator=g)
+    if a.relu_input:
+        x = torch.relu(x)
     y = ops.conv3d_bn_act(x, pc, algo=a.algo or None, splits=a.splits or None)
     res = torch.randn_like(y) if a.res else None
     torch.cuda.synchronize()
