@@ -26,8 +26,8 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 // tiles share operand panels -> same L2).  Bijective for any grid size.  Speed only.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   constexpr int NX = 8;
-  const int q = nwg / NX, r = nwg % NX;
-  const int xcd = bid % NX, k = bid / NX;
+  const int q = nwg >> 3, r = nwg & 7;  // unsigned-style shifts: no signed-division fix-ups
+  const int xcd = bid & 7, k = bid >> 3;
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + k;
 }

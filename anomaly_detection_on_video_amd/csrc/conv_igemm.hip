@@ -27,6 +27,39 @@
 
 namespace advhip {
 
+// Division by a launch-invariant divisor as multiply-high + shifts (exact for every 32-bit n).  A
+// runtime integer division costs ~40 VALU instructions on gfx950; a new workgroup's index arithmetic
+// competes with the MFMA streams of the older workgroups on its CU, so it has to be short.
+struct FastDiv {
+  unsigned mul, sh1, sh2, d;
+  __host__ static FastDiv make(unsigned d) {
+    FastDiv f;
+    f.d = d;
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    f.mul = (unsigned)(((1ull << l) - d) * (1ull << 32) / d + 1);
+    f.sh1 = l > 1 ? 1 : l;
+    f.sh2 = l > 0 ? l - 1 : 0;
+    if (l == 0) { f.mul = 0; f.sh1 = 0; f.sh2 = 0; }  // d == 1
+    return f;
+  }
+  __device__ __forceinline__ unsigned div(unsigned n) const {
+    const unsigned t = __umulhi(mul, n);
+    return (t + ((n - t) >> sh1)) >> sh2;
+  }
+};
+
+// bits [lo, hi) set; 0 <= lo, hi <= 31
+__device__ __forceinline__ unsigned bit_range(int lo, int hi) {
+  return hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+}
+// which taps d in [0, k) of a window starting at coordinate c0 fall inside [0, n): one bit per tap
+__device__ __forceinline__ unsigned tap_bits(int c0, int k, int n) {
+  const int lo = c0 < 0 ? -c0 : 0;
+  const int hi = (n - c0) < k ? (n - c0) : k;
+  return bit_range(lo < 31 ? lo : 31, hi < 0 ? 0 : hi);
+}
+
 struct ConvArgs {
   const float* x;
   const float* w;     // [Kpad][Cout]
@@ -49,6 +82,7 @@ struct ConvArgs {
   int pad_off;        // pt*HW + ph*W + pw: makes every per-lane window origin offset non-negative
   unsigned x_bytes;   // buffer range of x (plus pad_off*4)
   unsigned w_bytes;   // buffer range of the packed weights (LDS-DMA kernel)
+  FastDiv dTHWo, dHWo, dWo, dTilesN, dSplits;
 };
 
 template <int VW>
@@ -111,7 +145,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[B
     const int mm = m0 + wm * Cfg::WM + rcol;  // this lane's 4 consecutive m in the read phase
     const bool mok = mm < a.M;                // M % 4 == 0 here, so the group is all-in or all-out
     int bb = 0, pp = 0;
-    if (mok) { bb = mm / a.THWo; pp = mm - bb * a.THWo; }
+    if (mok) { bb = (int)a.dTHWo.div((unsigned)mm); pp = mm - bb * a.THWo; }
 #pragma unroll
     for (int jn = 0; jn < FN; ++jn) {
       // write phase: 4*FM consecutive m per lane for channel row li
@@ -364,13 +398,13 @@ __global__ __launch_bounds__(256) void conv3d_igemm_fast_kernel(const ConvArgs a
   const int ntiles = a.tiles_m * a.tiles_n;
   int L, split;
   if (a.splits > 1) {
-    split = blockIdx.x % a.splits;
-    L = blockIdx.x / a.splits;
+    L = (int)a.dSplits.div(blockIdx.x);
+    split = (int)blockIdx.x - L * a.splits;
   } else {
     split = 0;
     L = xcd_remap(blockIdx.x, ntiles);
   }
-  const int tile_n = L % a.tiles_n, tile_m = L / a.tiles_n;
+  const int tile_m = (int)a.dTilesN.div((unsigned)L), tile_n = L - tile_m * a.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- this thread's A column: window origin (voffset) and tap-validity mask ------------------
@@ -380,20 +414,18 @@ __global__ __launch_bounds__(256) void conv3d_igemm_fast_kernel(const ConvArgs a
   unsigned vbase = OOB;
   unsigned vmask = 0;
   if (m < a.M) {
-    const int b = m / a.THWo;
+    const int b = (int)a.dTHWo.div((unsigned)m);
     const int p = m - b * a.THWo;
-    const int ot = p / a.HWo;
+    const int ot = (int)a.dHWo.div((unsigned)p);
     const int q = p - ot * a.HWo;
-    const int oh = q / a.Wo;
+    const int oh = (int)a.dWo.div((unsigned)q);
     const int ow = q - oh * a.Wo;
     const int it0 = ot * a.st - a.pt, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
     vbase = (unsigned)(b * a.Cin * a.THW + it0 * a.HW + ih0 * a.W + iw0 + a.pad_off) * 4u;
     if constexpr (CHECK) {
       // a tap (dt,dh,dw) is inside the input iff each coordinate is: keep one bit per coordinate
       // value (bits 0-9: dt, 10-19: dh, 20-29: dw); the table holds the three bits a row needs
-      for (int dt = 0; dt < a.kt_; ++dt) vmask |= ((unsigned)(it0 + dt) < (unsigned)a.T ? 1u : 0u) << dt;
-      for (int dh = 0; dh < a.kh_; ++dh) vmask |= ((unsigned)(ih0 + dh) < (unsigned)a.H ? 1u : 0u) << (10 + dh);
-      for (int dw = 0; dw < a.kw_; ++dw) vmask |= ((unsigned)(iw0 + dw) < (unsigned)a.W ? 1u : 0u) << (20 + dw);
+      vmask = tap_bits(it0, a.kt_, a.T) | (tap_bits(ih0, a.kh_, a.H) << 10) | (tap_bits(iw0, a.kw_, a.W) << 20);
     }
   }
   const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) - a.pad_off, 0, a.x_bytes, 0x00020000);
@@ -576,8 +608,23 @@ __device__ __forceinline__ void lds_wait(Frag<NA>& a, Frag<NB>& b) {
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a.v), "+v"(b.v) : "n"(CNT));
 }
 
+// Waves per SIMD the register allocator must leave room for = the residency LDS allows.  The
+// matrix pipe is only kept busy while other workgroups' MFMA loops cover a workgroup's prologue and
+// epilogue (in-kernel stamps: ~12 of 66 us per tile at K = 768), so one more resident workgroup per CU
+// is worth more than spare registers: without the attribute hipcc allocates 51 VGPR + 36 AGPR for the
+// 64x64x16 kernel (5 waves/SIMD) although LDS admits 6.
+template <int BM, int BN, int BK, int NS>
+constexpr int dma_waves_per_simd() {
+  constexpr int ring = NS * BK * (BM + BN), st = IgemmCfg<BM, BN, BK>::ST_FLOATS;
+  constexpr int lds_bytes = (ring > st ? ring : st) * 4;
+  constexpr int by_lds = 163840 / lds_bytes;  // 256-thread workgroups = one wave per SIMD each
+  if (BM * BN >= 128 * 128) return by_lds < 2 ? by_lds : 2;  // 64 accumulators: 3 waves would spill
+  return by_lds > 8 ? 8 : (by_lds < 1 ? 1 : by_lds);
+}
+
 template <int BM, int BN, int BK, bool CHECK, int NS = 3>
-__global__ __launch_bounds__(256) void conv3d_igemm_dma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dma_waves_per_simd<BM, BN, BK, NS>(), 8)))
+void conv3d_igemm_dma_kernel(const ConvArgs a) {
   using Cfg = IgemmCfg<BM, BN, BK>;
   using D = DmaCfg<BM, BN, BK>;
   constexpr int FM = Cfg::FM, FN = Cfg::FN, KR = D::KR, LA = D::LA, LB = D::LB, KS = BK / 4;
@@ -593,15 +640,20 @@ __global__ __launch_bounds__(256) void conv3d_igemm_dma_kernel(const ConvArgs a)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntiles = a.tiles_m * a.tiles_n;
+  const int nitems = ntiles * a.splits;
+  // Persistent form: the grid may be smaller than the number of (tile, K-slice) work items; each
+  // workgroup then walks items blockIdx.x, blockIdx.x + gridDim.x, ... (a grid of nitems runs the
+  // body once).  Saves the workgroup re-dispatch between 50-microsecond tiles.
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
   int L, split;
   if (a.splits > 1) {
-    split = blockIdx.x % a.splits;
-    L = blockIdx.x / a.splits;
+    L = (int)a.dSplits.div((unsigned)item);
+    split = item - L * a.splits;
   } else {
     split = 0;
-    L = xcd_remap(blockIdx.x, ntiles);
+    L = xcd_remap(item, ntiles);
   }
-  const int tile_n = L % a.tiles_n, tile_m = L / a.tiles_n;
+  const int tile_m = (int)a.dTilesN.div((unsigned)L), tile_n = L - tile_m * a.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int ml = tid % BM;
@@ -610,18 +662,16 @@ __global__ __launch_bounds__(256) void conv3d_igemm_dma_kernel(const ConvArgs a)
   unsigned vbase = OOB;
   unsigned vmask = 0;
   if (m < a.M) {
-    const int b = m / a.THWo;
+    const int b = (int)a.dTHWo.div((unsigned)m);
     const int p = m - b * a.THWo;
-    const int ot = p / a.HWo;
+    const int ot = (int)a.dHWo.div((unsigned)p);
     const int q = p - ot * a.HWo;
-    const int oh = q / a.Wo;
+    const int oh = (int)a.dWo.div((unsigned)q);
     const int ow = q - oh * a.Wo;
     const int it0 = ot * a.st - a.pt, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
     vbase = (unsigned)(b * a.Cin * a.THW + it0 * a.HW + ih0 * a.W + iw0 + a.pad_off) * 4u;
     if constexpr (CHECK) {
-      for (int dt = 0; dt < a.kt_; ++dt) vmask |= ((unsigned)(it0 + dt) < (unsigned)a.T ? 1u : 0u) << dt;
-      for (int dh = 0; dh < a.kh_; ++dh) vmask |= ((unsigned)(ih0 + dh) < (unsigned)a.H ? 1u : 0u) << (10 + dh);
-      for (int dw = 0; dw < a.kw_; ++dw) vmask |= ((unsigned)(iw0 + dw) < (unsigned)a.W ? 1u : 0u) << (20 + dw);
+      vmask = tap_bits(it0, a.kt_, a.T) | (tap_bits(ih0, a.kh_, a.H) << 10) | (tap_bits(iw0, a.kw_, a.W) << 20);
     }
   }
   const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) - a.pad_off, 0, a.x_bytes, 0x00020000);
@@ -734,6 +784,8 @@ __global__ __launch_bounds__(256) void conv3d_igemm_dma_kernel(const ConvArgs a)
   }
   __syncthreads();  // every wave is done with the ring before the epilogue reuses it as staging
   igemm_epilogue<BM, BN, BK>(a, acc, smem, split, m0, n0, wave, lane);
+  __syncthreads();  // ... and with the staging before the next item's DMA lands in it
+  }  // item loop
 }
 
 // y = act(sum_s slab[s] * scale[c] + shift[c] (+ res)), slabs in NCDHW like y
@@ -978,6 +1030,9 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
   a.HWo = a.Ho * a.Wo; a.THWo = a.To * a.HWo;
   a.HW = d->H * d->W; a.THW = d->T * a.HW;
   a.relu = d->relu;
+  a.dTHWo = FastDiv::make((unsigned)a.THWo);
+  a.dHWo = FastDiv::make((unsigned)a.HWo);
+  a.dWo = FastDiv::make((unsigned)a.Wo);
   a.vw = (a.THWo % 4 == 0) ? 4 : (a.THWo % 2 == 0 ? 2 : 1);
 
   const Choice c = choose(d, M, g.Kpad);
@@ -1016,7 +1071,15 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
   }
   a.tiles_m = (int)((M + BM - 1) / BM);
   a.tiles_n = d->Cout / BN;
-  const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * c.splits));
+  a.dTilesN = FastDiv::make((unsigned)a.tiles_n);
+  a.dSplits = FastDiv::make((unsigned)c.splits);
+  dim3 grid((unsigned)(a.tiles_m * a.tiles_n * c.splits));
+  if (c.algo >= ADVHIP_ALGO_DMA_BASE) {
+    // persistent launch of the LDS-DMA kernel: at most `slots` workgroups per CU stay resident and
+    // loop over the work items (ADVHIP_PERSISTENT_SLOTS, 0 = one workgroup per item)
+    static const int slots = getenv("ADVHIP_PERSISTENT_SLOTS") ? atoi(getenv("ADVHIP_PERSISTENT_SLOTS")) : 0;
+    if (slots > 0 && grid.x > (unsigned)(256 * slots)) grid.x = 256u * slots;
+  }
   hipStream_t st = (hipStream_t)stream;
   // BK = 32 needs Kpad % 32 == 0: the packed weights are padded to 16 rows only, but the k-table
   // marks rows >= K invalid and the weight rows read beyond Kpad must exist -> require it.
