@@ -94,7 +94,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("ADVHIP_LIBRARY") or LIB_PATH  # ADVHIP_LIBRARY: another build of the same ABI (diagnostic builds)
     if not os.path.exists(p):
         raise HipExtensionError(
             f"{p} not found: the HIP extension has not been built. Run "

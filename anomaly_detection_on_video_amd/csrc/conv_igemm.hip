@@ -632,6 +632,20 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   static_assert(LB >= 1 && LA >= 1 && (NS - 2) * (LA + LB) <= 63, "tile / vmcnt budget");
   constexpr unsigned OOB = 0xFFFFFF00u;
   constexpr int RING = NS * D::STAGE;
+  // Diagnostic builds only (-DADVHIP_DIAG=bits, tools/diag_build.sh; results are wrong, timing is the point):
+  // 4 = the A rows of a wave as ONE 16-byte LDS-DMA instead of LA 4-byte ones, 8 = no A loads, 16 = no B loads.
+#ifdef ADVHIP_DIAG
+  constexpr int DIAG = ADVHIP_DIAG;
+#else
+  constexpr int DIAG = 0;
+#endif
+  constexpr int LAI = (DIAG & 8) ? 0 : (DIAG & 4) ? 1 : LA;  // A / B LDS-DMA instructions actually issued per wave per k-tile
+  constexpr int LBI = (DIAG & 16) ? 0 : LB;
+#if defined(ADVHIP_DIAG) && defined(__HIP_DEVICE_COMPILE__)  // (hipcc's host pass drops the kernel stub when it sees 16 here)
+  constexpr int ASZ = (DIAG & 4) ? 16 : 4;  // bytes per lane of an A LDS-DMA
+#else
+  constexpr int ASZ = 4;
+#endif
   constexpr int SMEM = RING > Cfg::ST_FLOATS ? RING : Cfg::ST_FLOATS;
 
   __shared__ __attribute__((aligned(16))) float smem[SMEM];
@@ -690,15 +704,20 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
     float* As = smem + stage * D::STAGE;
     float* Bs = As + BK * BM;
 #pragma unroll
-    for (int j = 0; j < LA; ++j) {
-      if (j * nparts / LA != part) continue;
+    for (int j = 0; j < LAI; ++j) {
+      if (j * nparts / (LAI ? LAI : 1) != part) continue;
       const int krow = kr * LA + j;
       unsigned voff = vbase;
       if constexpr (CHECK) voff = ((vmask & (unsigned)ent[2 * j + 1]) == (unsigned)ent[2 * j + 1]) ? vbase : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(As + krow * BM + a_wave_col), 4, voff, ent[2 * j], 0, 0);
+      if constexpr (DIAG & 32) {  // the access pattern of a channels-last gather: 8 rows x 128 B per wave-instruction
+        voff = (unsigned)(((m0 >> 1) + wave * 8 + (lane >> 3)) * a.Cin * 4 + (((k0 >> 5) * 32) % a.Cin) * 4 + (lane & 7) * 16);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(As + krow * BM + a_wave_col), ASZ, voff, 0, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(As + krow * BM + a_wave_col), ASZ, voff, ent[2 * j], 0, 0);
+      }
     }
 #pragma unroll
-    for (int j = 0; j < LB; ++j) {
+    for (int j = 0; j < LBI; ++j) {
       if (j * nparts / LB != part) continue;
       const int row0 = (wave * LB + j) * RPW;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(Bs + row0 * BN), 16, wvoff, ((k0 + row0) * a.Cout + n0) * 4, 0, 0);
@@ -733,9 +752,9 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   };
 
   // k-step ks of a stage sits ks*4 rows further down both tiles -> immediate offsets.
-  // `pre` >= 0: also issue tile (pre) into ring stage `pstage`, one slice per k-step.
-  auto compute = [&](auto pre_c, int stage, int pre_k0, int pstage) {
-    constexpr bool PRE = decltype(pre_c)::value;
+  // `pre`: also issue tile pre_k0 into ring stage `pstage`, one slice per k-step (a wave-uniform branch around
+  // the loads only: one copy of the MFMA body, so the accumulators keep their registers across iterations).
+  auto compute = [&](bool pre, int stage, int pre_k0, int pstage) {
     const unsigned aa = a_addr0 + (unsigned)(stage * D::STAGE) * 4u;
     const unsigned ba = b_addr0 + (unsigned)(stage * D::STAGE) * 4u;
     Frag<FM> fa[2];
@@ -752,7 +771,8 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
         lds_wait<0>(fa[ks & 1], fb[ks & 1]);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (PRE) issue_part(pre_k0, pstage, ks, KS);
+      if (pre) issue_part(pre_k0, pstage, ks, KS);
+      __builtin_amdgcn_sched_barrier(0);
       mfma_step(fa[ks & 1], fb[ks & 1]);
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -770,16 +790,13 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   for (int kt = kt0; kt < kt1; ++kt) {
     // tile kt has landed once only the loads of the younger tiles in flight (<= NS-2) are outstanding
     const int younger = kt1 - 1 - kt;
-    if (NS == 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LA + LB)) : "memory");
-    else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA + LB) : "memory");
+    if (NS == 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LAI + LBI)) : "memory");
+    else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LAI + LBI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");  // all waves' parts of tile kt are in LDS; stage (kt-1)%NS is free
-    if (kt + NS - 1 < kt1) {
-      sload_entries<LA>(ktab2, ((kt + NS - 1) * BK + kr * LA) * 8, ent);
-      compute(std::true_type{}, stage, (kt + NS - 1) * BK, stage == 0 ? NS - 1 : stage - 1);
-    } else {
-      compute(std::false_type{}, stage, 0, 0);
-    }
+    const bool pre = kt + NS - 1 < kt1;
+    if (pre) sload_entries<LA>(ktab2, ((kt + NS - 1) * BK + kr * LA) * 8, ent);
+    compute(pre, stage, (kt + NS - 1) * BK, stage == 0 ? NS - 1 : stage - 1);
     stage = stage == NS - 1 ? 0 : stage + 1;
   }
   __syncthreads();  // every wave is done with the ring before the epilogue reuses it as staging
@@ -1053,8 +1070,9 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
     // timing-only diagnostic (cdna_hip_programming.md section 7): zero-record descriptors make the
     // buffer unit drop every operand load while the instruction stream, waits and barriers stay, which
     // prices the memory side of the kernel.  Outputs are wrong by construction.
-    static const bool zero_records = getenv("ADVHIP_DEBUG_ZERO_RECORDS") != nullptr;
-    if (zero_records) a.x_bytes = a.w_bytes = 0;
+    static const int zero_records = getenv("ADVHIP_DEBUG_ZERO_RECORDS") ? atoi(getenv("ADVHIP_DEBUG_ZERO_RECORDS")) : 0;
+    if (zero_records & 1) a.x_bytes = 0;  // timing diagnostic: every activation load is out of range -> returns 0, no memory access
+    if (zero_records & 2) a.w_bytes = 0;  // ... every weight load
   }
   ADVHIP_REQUIRE(d->Cout % BN == 0, "conv3d: Cout=%d not a multiple of the %d-wide N tile", d->Cout, BN);
   ADVHIP_REQUIRE(g.Kpad % BK == 0 || BK == 16, "conv3d: internal: Kpad");

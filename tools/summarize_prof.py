@@ -4,7 +4,7 @@ conv-stack time per forward from the kernel trace (to compare with bench.py's HI
 and optionally FETCH_SIZE / WRITE_SIZE PMC passes.
 
     python tools/summarize_prof.py --trace gpurun_out/prof_x/runc --bench gpurun_out/prof_x.log \
-        [--fetch DIR --write DIR] --out profiles/r01_final
+        [--fetch DIR --write DIR] [--mfma DIR] --out profiles/r01_final
 """
 import argparse
 import collections
@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--bench", default="")
     ap.add_argument("--fetch", default="")
     ap.add_argument("--write", default="")
+    ap.add_argument("--mfma", default="", help="PMC pass with SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     rows = load(os.path.join(a.trace, "*_kernel_trace.csv"))
@@ -101,6 +102,28 @@ def main():
             res[fam] = {"fetch_kb": f, "write_kb": w, "bytes_corrected": 2 * f * 1024 + w * 1024}
         with open(a.out + "_traffic.json", "w") as fp:
             json.dump(res, fp, indent=1)
+    if a.mfma:
+        # matrix-pipe utilisation from counters: SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of all
+        # 1024 SIMDs, GRBM_GUI_ACTIVE the active cycles of the 8 XCDs (MI355X_MICROARCH.md counters).
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        for r in load(os.path.join(a.mfma, "*_counter_collection.csv")):
+            if family(r["Kernel_Name"]) != "conv" or "splitk_reduce" in r["Kernel_Name"]:
+                continue
+            n = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            for key in (n, "all conv kernels"):
+                agg[key][r["Counter_Name"]] += float(r["Counter_Value"])
+                if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                    agg[key]["launches"] += 1
+        out.append("\n## Matrix-pipe utilisation (PMC pass: SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE, SQ_INSTS_MFMA)\n\n")
+        out.append("busy % = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs); fp32 16x16x4 MFMA = 32 busy cycles each\n\n")
+        out.append("| kernel | launches | MFMA instructions | MFMA busy cycles per SIMD | active cycles | MFMA pipe busy |\n|---|---:|---:|---:|---:|---:|\n")
+        mf = {}
+        for n, c in sorted(agg.items(), key=lambda kv: -kv[1]["SQ_VALU_MFMA_BUSY_CYCLES"]):
+            busy, act = c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0, c["GRBM_GUI_ACTIVE"] / 8.0
+            out.append("| `%s` | %d | %.4g | %.4g | %.4g | %.1f %% |\n" % (n, c["launches"], c["SQ_INSTS_MFMA"], busy, act, 100 * busy / max(act, 1)))
+            mf[n] = {"launches": c["launches"], "mfma_insts": c["SQ_INSTS_MFMA"], "busy_per_simd": busy, "active": act, "busy_frac": busy / max(act, 1)}
+        with open(a.out + "_mfma.json", "w") as fp:
+            json.dump(mf, fp, indent=1)
     with open(a.out + "_summary.md", "w") as fp:
         fp.writelines(out)
     print("".join(out))
