@@ -633,7 +633,8 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   constexpr unsigned OOB = 0xFFFFFF00u;
   constexpr int RING = NS * D::STAGE;
   // Diagnostic builds only (-DADVHIP_DIAG=bits, tools/diag_build.sh; results are wrong, timing is the point):
-  // 4 = the A rows of a wave as ONE 16-byte LDS-DMA instead of LA 4-byte ones, 8 = no A loads, 16 = no B loads.
+  // 4 = the A rows of a wave as ONE 16-byte LDS-DMA instead of LA 4-byte ones, 8 = no A loads, 16 = no B loads,
+  // 32 = A in a channels-last access pattern.
 #ifdef ADVHIP_DIAG
   constexpr int DIAG = ADVHIP_DIAG;
 #else
@@ -698,7 +699,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   const int a_wave_col = (wave % (BM / 64)) * 64;  // which 64-float piece of an A row this wave fills
 
   // wave group kr fills k-rows [kr*LA, (kr+1)*LA) of a tile: its table entries are contiguous.
-  // A tile's loads are issued in KS slices (issue_part) so they can sit between the MFMA groups.
+  // (issue_part can also issue a 1/nparts slice of a tile's loads; the product issues whole tiles.)
   int ent[2 * LA];
   auto issue_part = [&](int k0, int stage, int part, int nparts) {
     float* As = smem + stage * D::STAGE;
@@ -752,13 +753,17 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   };
 
   // k-step ks of a stage sits ks*4 rows further down both tiles -> immediate offsets.
-  // `pre`: also issue tile pre_k0 into ring stage `pstage`, one slice per k-step (a wave-uniform branch around
-  // the loads only: one copy of the MFMA body, so the accumulators keep their registers across iterations).
+  // `pre`: also issue tile pre_k0 into ring stage `pstage` (a wave-uniform branch around the loads only: one copy of
+  // the MFMA body, so the accumulators keep their registers across iterations).
   auto compute = [&](bool pre, int stage, int pre_k0, int pstage) {
     const unsigned aa = a_addr0 + (unsigned)(stage * D::STAGE) * 4u;
     const unsigned ba = b_addr0 + (unsigned)(stage * D::STAGE) * 4u;
     Frag<FM> fa[2];
     Frag<FN> fb[2];
+    // the whole next tile's loads go out right after the barrier (micro-benchmark tools/dma_ceiling.hip modes 9/10 and
+    // an A/B on the stack: one slice per k-step between the MFMA groups is 0.3-0.9 % slower)
+    if (pre) issue_part(pre_k0, pstage, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
     lds_read<FM, 0>(fa[0], aa);
     lds_read<FN, 0>(fb[0], ba);
     auto body = [&](auto ks_c) {
@@ -770,8 +775,6 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
       } else {
         lds_wait<0>(fa[ks & 1], fb[ks & 1]);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      if (pre) issue_part(pre_k0, pstage, ks, KS);
       __builtin_amdgcn_sched_barrier(0);
       mfma_step(fa[ks & 1], fb[ks & 1]);
       __builtin_amdgcn_sched_barrier(0);
