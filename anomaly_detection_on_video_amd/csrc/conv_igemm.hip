@@ -661,12 +661,15 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   // body once).  Saves the workgroup re-dispatch between 50-microsecond tiles.
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
   int L, split;
+  // each XCD works on a contiguous range of (tile, K-slice) items: the K-slices of a tile and the n-tiles of an
+  // m-tile (which re-read the same activation rows) meet in one L2
+  const int it = xcd_remap(item, nitems);
   if (a.splits > 1) {
-    L = (int)a.dSplits.div((unsigned)item);
-    split = item - L * a.splits;
+    L = (int)a.dSplits.div((unsigned)it);
+    split = it - L * a.splits;
   } else {
     split = 0;
-    L = xcd_remap(item, ntiles);
+    L = it;
   }
   const int tile_m = (int)a.dTilesN.div((unsigned)L), tile_n = L - tile_m * a.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
