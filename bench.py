@@ -180,7 +180,7 @@ def main():
     achieved = args.batch * GFLOP_PER_CLIP / conv_ms_avg  # GFLOP/ms == TFLOP/s
 
     h2d = h2d_u8 = None
-    if args.h2d and rank == 0:
+    if args.h2d and world == 1:  # single-process extra; with N > 1 a rank-0-only step would leave the collective hanging
         xh = x.cpu().pin_memory()
         for _ in range(2):
             stream.step(xh.to(dev, non_blocking=True))
