@@ -90,6 +90,14 @@ def _build_ktab(pc: PackedConv, thw: Tuple[int, int, int]) -> torch.Tensor:
     return ktab
 
 
+def ensure_ktab(pc: PackedConv, thw: Tuple[int, int, int]) -> torch.Tensor:
+    """The gather table of `pc` for input dims (T,H,W), built on the current stream on first use."""
+    ktab = pc.ktabs.get(thw)
+    if ktab is None:
+        ktab = pc.ktabs[thw] = _build_ktab(pc, thw)
+    return ktab
+
+
 def pack_conv(weight: torch.Tensor, gamma, beta, mean, var, eps: float, stride, padding, name: str = "",
               algo: int = _lib.ALGO_AUTO) -> PackedConv:
     """Pack one conv (torch layout (Cout,Cin,kt,kh,kw)) + its eval BatchNorm for the HIP kernels."""
@@ -105,16 +113,18 @@ def pack_conv(weight: torch.Tensor, gamma, beta, mean, var, eps: float, stride, 
     return pc
 
 
-_WORKSPACES: Dict[torch.device, torch.Tensor] = {}
+_WORKSPACES: Dict[Tuple[torch.device, int], torch.Tensor] = {}
 
 
 def workspace(dev: torch.device, nbytes: int) -> Optional[torch.Tensor]:
-    """Grow-only per-device scratch for the split-K partial slabs (caller-owned, per the C ABI)."""
+    """Grow-only scratch for the split-K partial slabs (caller-owned, per the C ABI), one per
+    (device, launch stream): launches on different streams may run at the same time."""
     if nbytes <= 0:
         return None
-    ws = _WORKSPACES.get(dev)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
-        ws = _WORKSPACES[dev] = torch.empty(((nbytes + 3) // 4,), device=dev, dtype=torch.float32)
+        ws = _WORKSPACES[key] = torch.empty(((nbytes + 3) // 4,), device=dev, dtype=torch.float32)
     return ws
 
 
@@ -131,10 +141,7 @@ def conv3d_bn_act(x: torch.Tensor, pc: PackedConv, relu: bool = True, residual: 
     y = out if out is not None else torch.empty((B, pc.cout, to, ho, wo), device=x.device, dtype=torch.float32)
     if residual is not None and residual.shape != y.shape:
         raise ValueError(f"{pc.name}: residual {tuple(residual.shape)} != output {tuple(y.shape)}")
-    key = (T, H, W)
-    ktab = pc.ktabs.get(key)
-    if ktab is None:
-        ktab = pc.ktabs[key] = _build_ktab(pc, key)
+    ktab = ensure_ktab(pc, (T, H, W))
     if algo is not None and splits is None:
         splits = 1  # an explicitly pinned tile runs unsplit unless the caller also pins the split
     d = pc.desc(B, T, H, W, relu, algo, splits)

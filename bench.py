@@ -168,7 +168,10 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # conv-stack duration per step from the HIP events recorded on the launch stream
+    # backbone duration per step from the HIP events recorded on the launch stream.  One stream: [start, (pool
+    # start, end) x3, end] -> conv stack = span minus the pool launches.  Several streams (the default splits
+    # the batch over two): [start, end] around fork..join on the launch stream; pools overlap convs there, so
+    # the span (pools included) is the denominator -- a lower bound on the conv stack's own rate.
     per = len(events) // max(args.steps, 1)
     conv_ms = []
     for s in range(args.steps):
@@ -178,6 +181,7 @@ def main():
         conv_ms.append(total - pools)
     conv_ms_avg = sum(conv_ms) / len(conv_ms)
     achieved = args.batch * GFLOP_PER_CLIP / conv_ms_avg  # GFLOP/ms == TFLOP/s
+    n_streams = backbone._n_streams(args.batch)
 
     h2d = h2d_u8 = None
     if args.h2d and world == 1:  # single-process extra; with N > 1 a rank-0-only step would leave the collective hanging
@@ -230,7 +234,8 @@ def main():
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(args.batch),
                 "traffic_unit": "bytes per launch set (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes in profiles/)",
-                "kernel": "conv3d fp32-MFMA stack (53 launches per step on rank 0)",
+                "kernel": "conv3d fp32-MFMA stack (53 launches per step on rank 0)" if n_streams == 1 else
+                f"conv3d fp32-MFMA stack, batch split over {n_streams} HIP streams (2 x 53 launches per step on rank 0; time = fork..join span, pools included)",
                 "flop_per_launch_set": args.batch * GFLOP_PER_CLIP * 1e9, "avg_ms_per_launch_set": round(conv_ms_avg, 4),
             },
         }

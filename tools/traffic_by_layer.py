@@ -2,7 +2,7 @@
 """Per-conv HBM traffic from the rocprofv3 PMC passes of bench.py (FETCH_SIZE / WRITE_SIZE, one value per dispatch)
 next to the compulsory bytes of the layer (input once + weights + residual + output), B = 32.
 
-    python tools/traffic_by_layer.py gpurun_out/final2/fetch/runc gpurun_out/final2/write/runc
+    python tools/traffic_by_layer.py gpurun_out/final2/fetch/runc gpurun_out/final2/write/runc [stream parts per forward, default 2]
 """
 import csv
 import glob
@@ -50,9 +50,26 @@ def per_dispatch(d):
     return rows
 
 
-def last_forward(rows):
+def last_forward(rows, parts=2):
+    """Per conv of the plan: [counter KB, ns, kernel] summed over the stream parts of the last forward (dispatch ids follow
+    launch order: part 0's whole chain, then part 1's)."""
     ends = [i for i, r in enumerate(rows) if "global_avgpool" in r["Kernel_Name"]]
-    seg = rows[ends[-2] + 1 : ends[-1] + 1]
+    total = None
+    for p in range(parts):
+        e = len(ends) - parts + p
+        one = one_chain(rows[ends[e - 1] + 1 : ends[e] + 1])
+        if total is None:
+            total = one
+        else:
+            for t, o in zip(total, one):
+                t[0] += o[0]
+                t[1] += o[1]
+                if o[2] != t[2]:
+                    t[2] += " | " + o[2]
+    return total
+
+
+def one_chain(seg):
     convs = []
     for r in seg:
         n = r["Kernel_Name"]
@@ -66,8 +83,9 @@ def last_forward(rows):
 
 
 def main():
-    f = last_forward(per_dispatch(sys.argv[1]))
-    w = last_forward(per_dispatch(sys.argv[2]))
+    parts = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    f = last_forward(per_dispatch(sys.argv[1]), parts)
+    w = last_forward(per_dispatch(sys.argv[2]), parts)
     L = layers()
     assert len(f) == len(L) == len(w), (len(f), len(w), len(L))
     print("| conv | kernel | compulsory read MB | FETCH_SIZE x2 MB | ratio | compulsory write MB | WRITE_SIZE MB | us | TFLOP/s |\n|---|---|---:|---:|---:|---:|---:|---:|---:|")
