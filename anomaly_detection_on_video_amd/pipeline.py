@@ -38,6 +38,13 @@ class ExtractScoreStream:
         # (opt-in: measured neutral on throughput, the launches already overlap the backbone)
         self.use_graph = os.environ.get("ADV_SCORE_GRAPH") == "1"
         self._graphs: Dict[Tuple[int, int, int], Tuple[torch.cuda.CUDAGraph, torch.Tensor, torch.Tensor]] = {}
+        # step_async: consecutive steps alternate between `lanes` HIP streams (see step_async)
+        # (measured at B=32 on one MI355X: 1 lane + batch split over 2 streams 10.12 ms/step, 2 lanes 9.96, 3 lanes 9.65,
+        #  4 lanes 10.06, 6 lanes 9.89; lanes x an in-step batch split is slower than lanes alone)
+        self.lanes = int(os.environ.get("ADV_PIPELINE_LANES", "3"))
+        self._lane_streams: List[torch.cuda.Stream] = []
+        self._lane_next = 0
+        self._ordered: Optional[torch.cuda.Event] = None  # end of the previous step's gather + ingest
 
     @torch.no_grad()
     def step(self, local_clips: torch.Tensor) -> Tuple[torch.Tensor, List[Tuple[int, torch.Tensor]]]:
@@ -46,6 +53,48 @@ class ExtractScoreStream:
         feats = self.backbone(local_clips).reshape(local_clips.shape[0], -1)
         gathered = adist.all_gather_rows(feats) if self.world > 1 else feats
         return gathered, self.ingest(gathered)
+
+    @torch.no_grad()
+    def step_async(self, local_clips: torch.Tensor) -> "StepHandle":
+        """`step` without the implied ordering against the caller's stream: step i runs on lane i % lanes (a HIP
+        stream of its own: backbone, all-gather, ring ingest, scoring), so the backbone of step i+1 runs beside the
+        tail, the gather and the scoring of step i and memory-bound launches of one step overlap MFMA-bound ones of the
+        other.  Only the ring update (gather + ingest + scoring) is ordered step after step, by an event.  The
+        returned handle's `result()` makes the caller's current stream wait for the step."""
+        dev = self.ring.device
+        if self.lanes <= 1:
+            g, s = self.step(local_clips)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            return StepHandle(ev, g, s)
+        while len(self._lane_streams) < self.lanes:
+            self._lane_streams.append(torch.cuda.Stream(device=dev))
+        lane = self._lane_streams[self._lane_next]
+        self._lane_next = (self._lane_next + 1) % self.lanes
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(lane):
+            lane.wait_event(ready)
+            local_clips.record_stream(lane)
+            inner = getattr(self.backbone, "streams", 1)
+            try:
+                self.backbone.streams = 1  # whole-batch launches per lane; the overlap comes from the other lanes
+                feats = self.backbone(local_clips).reshape(local_clips.shape[0], -1)
+            finally:
+                self.backbone.streams = inner
+            if self._ordered is not None:
+                lane.wait_event(self._ordered)
+            gathered = adist.all_gather_rows(feats) if self.world > 1 else feats
+            scored = self.ingest(gathered)
+            self._ordered = torch.cuda.Event()
+            self._ordered.record(lane)
+        return StepHandle(self._ordered, gathered, scored)
+
+    def drain(self) -> None:
+        """Make the caller's current stream wait for every step issued by step_async."""
+        cur = torch.cuda.current_stream(self.ring.device)
+        if self._ordered is not None:
+            cur.wait_event(self._ordered)
 
     @torch.no_grad()
     def ingest(self, gathered: torch.Tensor) -> List[Tuple[int, torch.Tensor]]:
@@ -94,3 +143,19 @@ class ExtractScoreStream:
         x = mil_ops.add_magnitude(feats)  # (T, 10, 2049)
         video = x.unsqueeze(0).permute(0, 2, 1, 3).contiguous()
         return self.scorer(video=video).scores.reshape(-1)
+
+
+class StepHandle:
+    """Result of ExtractScoreStream.step_async: tensors produced on a lane stream."""
+
+    def __init__(self, done: torch.cuda.Event, gathered: torch.Tensor, scored: List[Tuple[int, torch.Tensor]]):
+        self._done, self._gathered, self._scored = done, gathered, scored
+
+    def result(self) -> Tuple[torch.Tensor, List[Tuple[int, torch.Tensor]]]:
+        """(gathered features, [(video, scores)]) after making the current stream wait for the step."""
+        cur = torch.cuda.current_stream(self._gathered.device)
+        cur.wait_event(self._done)
+        self._gathered.record_stream(cur)
+        for _v, sc in self._scored:
+            sc.record_stream(cur)
+        return self._gathered, self._scored

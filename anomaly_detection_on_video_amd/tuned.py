@@ -21,4 +21,8 @@ def table() -> Dict[str, Tuple[int, int]]:
 
 
 def lookup(key: str, default: Tuple[int, int]) -> Tuple[int, int]:
-    return table().get(key, default)
+    algo, splits = table().get(key, default)
+    cap = int(os.environ.get("ADV_MAX_SPLITS", "0"))  # experiment knob: cap the split-K factor of tuned entries
+    if cap > 0 and splits > cap:
+        splits = cap
+    return algo, splits

@@ -161,6 +161,20 @@ def test_stream_scores_match_oracle_end_to_end():
         video = torch.from_numpy(host_oracle.add_magnitude(f)).unsqueeze(0).permute(0, 2, 1, 3)
         ref = mgfn_oracle.mgfn_forward(video, msd).scores.reshape(-1)
         assert rel_err(s.cpu(), ref) < TOL
+    # the same stream through step_async (consecutive steps on alternating HIP stream lanes, only the ring
+    # update ordered): identical launches, so bit-identical features and scores
+    lanes = ExtractScoreStream(bb, sc, clips_per_video=3, ncrops=2, local_batch=4)
+    assert lanes.lanes == 3
+    handles = [lanes.step_async(x[i : i + 4].to(DEV)) for i in range(0, 12, 4)]
+    lanes.drain()
+    got = []
+    for k, h in enumerate(handles):
+        g, sc_list = h.result()
+        assert torch.equal(g, stream.ring[4 * k : 4 * k + 4])
+        got += sc_list
+    assert [v for v, _ in got] == [0, 1]
+    for (_v, a), (_w, b) in zip(got, scored):
+        assert torch.equal(a, b)
 
 
 def test_end_to_end_extract_segment_train_auc(tmp_path):
