@@ -38,6 +38,46 @@ def load_feature_extraction_model(model_name: str = "tushar-n-baseline", **facto
     return model, device
 
 
+_LANES: Dict[torch.device, list] = {}
+
+
+@torch.no_grad()
+def run_chunks_on_lanes(model, chunks, lanes: Optional[int] = None) -> torch.Tensor:
+    """Backbone forwards of independent chunks of crop-clips -> (sum of rows, 2048), in order.  One chunk: a plain
+    `model(chunk)` (which splits its batch over two streams itself).  Several: chunk i runs on HIP stream lane
+    i % lanes as whole-batch launches, so up to `lanes` forwards are in flight and one chunk's kernel tails and
+    memory-bound launches overlap another's MFMA-bound ones (same kernels, bit-identical rows; pipeline.py has the
+    measurements).  The caller's stream waits for every lane before the rows are concatenated."""
+    lanes = int(os.environ.get("ADV_PIPELINE_LANES", "3")) if lanes is None else lanes
+    if len(chunks) <= 1 or lanes <= 1 or not chunks[0].is_cuda:  # (CPU tensors: host-logic tests with a stand-in model)
+        return torch.cat([model(c.contiguous()).reshape(-1, 2048) for c in chunks], dim=0)
+    dev = chunks[0].device
+    pool = _LANES.setdefault(dev, [])
+    while len(pool) < lanes:
+        pool.append(torch.cuda.Stream(device=dev))
+    cur = torch.cuda.current_stream(dev)
+    ready = torch.cuda.Event()
+    ready.record(cur)
+    outs, inner = [], getattr(model, "streams", 1)
+    try:
+        model.streams = 1
+        for i, c in enumerate(chunks):
+            lane = pool[i % lanes]
+            with torch.cuda.stream(lane):
+                lane.wait_event(ready)
+                c = c.contiguous()
+                c.record_stream(lane)
+                out = model(c).reshape(-1, 2048)
+                done = torch.cuda.Event()
+                done.record(lane)
+            cur.wait_event(done)
+            out.record_stream(cur)
+            outs.append(out)
+    finally:
+        model.streams = inner
+    return torch.cat(outs, dim=0)
+
+
 @torch.no_grad()
 def extract_clip_batch(model, clips: torch.Tensor, max_crop_clips: int = 32, sharded: bool = False) -> torch.Tensor:
     """(B, ncrops, 16, 3, H, W) TenCrop'd clips -> (B, ncrops, 2048) features on the device.
@@ -59,10 +99,7 @@ def extract_clip_batch(model, clips: torch.Tensor, max_crop_clips: int = 32, sha
         folded = clips.to(dev, non_blocking=True).permute(0, 1, 3, 2, 4, 5).reshape(B * ncrops, clips.shape[3], clips.shape[2], *clips.shape[4:])
 
     def run(units: torch.Tensor) -> torch.Tensor:
-        outs = []
-        for i in range(0, units.shape[0], max_crop_clips):
-            outs.append(model(units[i : i + max_crop_clips].contiguous()).reshape(-1, 2048))
-        return torch.cat(outs, dim=0)
+        return run_chunks_on_lanes(model, [units[i : i + max_crop_clips] for i in range(0, units.shape[0], max_crop_clips)])
 
     rows = adist.sharded_map_rows(run, folded) if sharded else run(folded)
     return rows.reshape(B, ncrops, 2048)

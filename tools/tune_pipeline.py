@@ -25,7 +25,7 @@ from anomaly_detection_on_video_amd.models.mgfn import MGFNConfig, MGFNForVideoA
 from anomaly_detection_on_video_amd.pipeline import ExtractScoreStream  # noqa: E402
 from anomaly_detection_on_video_amd.weights import synth_i3d_state_dict, synth_module_state_dict  # noqa: E402
 
-FIXED = [(67, 1), (68, 1), (66, 1), (65, 1), (71, 1), (72, 1), (70, 1), (99, 1), (100, 1), (35, 1), (67, 2), (67, 3), (68, 2), (71, 2)]
+FIXED = [(a, s) for a in (67, 68, 66, 65, 71, 72, 70, 99, 100, 98, 35) for s in (1, 2, 3)]
 
 
 def main():
