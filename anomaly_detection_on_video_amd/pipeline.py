@@ -55,15 +55,19 @@ class ExtractScoreStream:
         return gathered, self.ingest(gathered)
 
     @torch.no_grad()
-    def step_async(self, local_clips: torch.Tensor) -> "StepHandle":
+    def step_async(self, local_clips: torch.Tensor, prepare=None) -> "StepHandle":
         """`step` without the implied ordering against the caller's stream: step i runs on lane i % lanes (a HIP
         stream of its own: backbone, all-gather, ring ingest, scoring), so the backbone of step i+1 runs beside the
         tail, the gather and the scoring of step i and memory-bound launches of one step overlap MFMA-bound ones of the
         other.  Only the ring update (gather + ingest + scoring) is ordered step after step, by an event.  The
-        returned handle's `result()` makes the caller's current stream wait for the step."""
+        returned handle's `result()` makes the caller's current stream wait for the step.
+
+        `prepare`: optional callable run on the lane before the backbone, e.g. the H2D copy of pinned host pixels
+        and the uint8 -> fp32 normalise/permute pass, so that PCIe transfers of one step overlap the other lanes'
+        compute (`lambda host_u8: mil_ops.normalize_permute_u8(host_u8.to(dev, non_blocking=True))`)."""
         dev = self.ring.device
         if self.lanes <= 1:
-            g, s = self.step(local_clips)
+            g, s = self.step(local_clips if prepare is None else prepare(local_clips))
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
             return StepHandle(ev, g, s)
@@ -75,7 +79,10 @@ class ExtractScoreStream:
         ready.record(torch.cuda.current_stream(dev))
         with torch.cuda.stream(lane):
             lane.wait_event(ready)
-            local_clips.record_stream(lane)
+            if prepare is not None:
+                local_clips = prepare(local_clips)
+            else:
+                local_clips.record_stream(lane)
             inner = getattr(self.backbone, "streams", 1)
             try:
                 self.backbone.streams = 1  # whole-batch launches per lane; the overlap comes from the other lanes

@@ -192,27 +192,26 @@ def main():
 
     h2d = h2d_u8 = None
     if args.h2d and world == 1:  # single-process extra; with N > 1 a rank-0-only step would leave the collective hanging
-        xh = x.cpu().pin_memory()
-        for _ in range(2):
-            stream.step(xh.to(dev, non_blocking=True))
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            stream.step(xh.to(dev, non_blocking=True))
-        torch.cuda.synchronize()
-        h2d = args.batch * args.steps / (time.perf_counter() - t1)
-        # same, but uint8 pixels over PCIe + on-device normalise/permute (4x fewer bytes)
+        # host buffers every step: the copy (and the uint8 pre-processing) is issued on the step's lane, so PCIe
+        # transfers overlap the other lanes' compute
         from anomaly_detection_on_video_amd import mil_ops
 
+        def timed(host, prep):
+            for _ in range(3):
+                stream.step_async(host, prepare=prep)
+            stream.drain()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                stream.step_async(host, prepare=prep)
+            stream.drain()
+            torch.cuda.synchronize()
+            return args.batch * args.steps / (time.perf_counter() - t1)
+
+        h2d = timed(x.cpu().pin_memory(), lambda h: h.to(dev, non_blocking=True))
+        # uint8 pixels over PCIe + on-device normalise/permute (4x fewer bytes)
         xu = torch.randint(0, 256, (args.batch, 16, 3, 224, 224), dtype=torch.uint8).pin_memory()
-        for _ in range(2):
-            stream.step(mil_ops.normalize_permute_u8(xu.to(dev, non_blocking=True)))
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            stream.step(mil_ops.normalize_permute_u8(xu.to(dev, non_blocking=True)))
-        torch.cuda.synchronize()
-        h2d_u8 = args.batch * args.steps / (time.perf_counter() - t1)
+        h2d_u8 = timed(xu, lambda h: mil_ops.normalize_permute_u8(h.to(dev, non_blocking=True)))
 
     if rank == 0:
         total_clips = args.batch * world * args.steps

@@ -175,6 +175,14 @@ def test_stream_scores_match_oracle_end_to_end():
     assert [v for v, _ in got] == [0, 1]
     for (_v, a), (_w, b) in zip(got, scored):
         assert torch.equal(a, b)
+    # host buffers handed to the lanes: the H2D copy runs on the step's lane (`prepare`)
+    hosted = ExtractScoreStream(bb, sc, clips_per_video=3, ncrops=2, local_batch=4)
+    pinned = x.pin_memory()
+    hs = [hosted.step_async(pinned[i : i + 4], prepare=lambda h: h.to(DEV, non_blocking=True)) for i in range(0, 12, 4)]
+    hosted.drain()
+    torch.cuda.synchronize()
+    assert torch.equal(hosted.ring, stream.ring)
+    assert [v for h in hs for v, _ in h.result()[1]] == [0, 1]
 
 
 def test_end_to_end_extract_segment_train_auc(tmp_path):
