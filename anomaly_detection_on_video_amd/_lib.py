@@ -32,10 +32,14 @@ ALGO_DMA_BASE = 64  # + tile id: fast gather + LDS-DMA staging into a 3-deep rin
 DMA_ALGOS = tuple(ALGO_DMA_BASE + a for a in (1, 2, 3, 4, 6, 7, 8))
 ALGO_DMA4_BASE = 96  # + tile id 2..4: 4-deep ring
 DMA4_ALGOS = tuple(ALGO_DMA4_BASE + a for a in (2, 3, 4))
+ALGO_BF16X3_BASE = 128  # + tile id 5 (128x128x32) / 6 (128x64x32): opt-in split-bf16 arithmetic (3 bf16 MFMAs per fragment)
+BF16X3_ALGOS = tuple(ALGO_BF16X3_BASE + a for a in (5, 6))
 
 
 def algo_tile(algo: int):
     """(BM, BN, BK) of an implicit-GEMM algorithm id."""
+    if algo >= ALGO_BF16X3_BASE:
+        algo -= ALGO_BF16X3_BASE
     if algo >= ALGO_DMA4_BASE:
         algo -= ALGO_DMA4_BASE
     if algo >= ALGO_DMA_BASE:
@@ -68,6 +72,7 @@ SIGNATURES = {
     "advhip_conv3d_out_dims": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "advhip_conv3d_packed_rows": (C.c_int, [C.POINTER(ConvDesc)]),
     "advhip_conv3d_pack_weight_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P]),
+    "advhip_conv3d_pack_weight_bf16x3": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P]),
     "advhip_conv3d_build_ktab": (C.c_int, [C.POINTER(ConvDesc), _P, _P]),
     "advhip_bn_fold_f32": (C.c_int, [_P, _P, _P, _P, C.c_float, _I, _P, _P, _P]),
     "advhip_conv3d_workspace_bytes": (_L, [C.POINTER(ConvDesc)]),

@@ -811,6 +811,192 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   }  // item loop
 }
 
+// ================================================================================================
+// Split-bf16 variant ("bf16x3"): every fp32 operand is split into two bf16 terms, x = hi + lo (+ <= 2^-17 |x|), and
+// the contraction runs as three bf16 MFMAs per fragment -- hi*hi + hi*lo + lo*hi -- accumulated in fp32
+// (v_mfma_f32_16x16x32_bf16: 8192 MACs in 16 cycles, 16x the fp32 MFMA rate, so 3 of them cost 3/16 of the fp32
+// instruction stream).  The dropped lo*lo term and the split residue bound the relative error of a product by ~2^-16;
+// results agree with the fp32 kernels to ~1e-5 (tests), inside the 1e-3 contract but not bit-comparable -- opt-in.
+//   tile 128 x BN x 32, 256 threads = 2x2 waves of 64 x BN/2 (the fp32 kernels' accumulator mapping, same epilogue);
+//   A: fp32 NCDHW gather as in the fast kernel (raw buffer loads, scalar tap offsets, coordinate mask), 16 consecutive
+//      k per thread, split in registers (v_cvt_pk_bf16_f32), written as [row][32 k] bf16 images (hi, lo), 80-byte rows
+//      (conflict-free ds_read_b128 of 16 rows x 16 B and ds_write_b128 of consecutive rows);
+//   B: weights pre-split on the device once ([2][Cout][Kpad] bf16, k contiguous), staged the same way;
+//   rows of an image are stored fragment-major (row position jm*16 + i holds m = FM*i + jm), so one ds_read_b128 per
+//   lane is a whole MFMA operand (8 k of one row).
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2v = __attribute__((ext_vector_type(2))) float;
+
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+  const f32x2v v = {x0, x1};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  const f32x2v r = {x0 - __builtin_bit_cast(float, hi << 16), x1 - __builtin_bit_cast(float, hi & 0xFFFF0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+}
+
+template <int BN, bool CHECK>
+__global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(const ConvArgs a) {
+  constexpr int BM = 128, BK = 32;
+  using Cfg = IgemmCfg<BM, BN, BK>;
+  constexpr int FM = Cfg::FM, FN = Cfg::FN;
+  static_assert(FM == 4 && (FN == 4 || FN == 2), "wave tile 64 x 64 or 64 x 32");
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  constexpr int PITCH = 80;                       // bytes per image row: 64 of data + 16 of padding
+  constexpr int A_IMG = BM * PITCH, B_IMG = BN * PITCH;
+  constexpr int TILE_BYTES = 2 * A_IMG + 2 * B_IMG;  // A hi, A lo, B hi, B lo
+  constexpr int SMEM_BYTES = TILE_BYTES > Cfg::ST_FLOATS * 4 ? TILE_BYTES : Cfg::ST_FLOATS * 4;
+  constexpr int NBC = BN * 4 / 256;               // 16-byte chunks of one B image per thread
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+  unsigned char* const Ah = smem;
+  unsigned char* const Al = smem + A_IMG;
+  unsigned char* const Bh = smem + 2 * A_IMG;
+  unsigned char* const Bl = smem + 2 * A_IMG + B_IMG;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = a.tiles_m * a.tiles_n;
+  const int it = xcd_remap((int)blockIdx.x, ntiles * a.splits);
+  int L, split;
+  if (a.splits > 1) {
+    L = (int)a.dSplits.div((unsigned)it);
+    split = it - L * a.splits;
+  } else {
+    split = 0;
+    L = it;
+  }
+  const int tile_m = (int)a.dTilesN.div((unsigned)L), tile_n = L - tile_m * a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- A: this thread fills image row p (fragment-major position) with k-half khalf (16 consecutive k)
+  const int p = tid & 127;
+  const int khalf = __builtin_amdgcn_readfirstlane(tid >> 7);
+  const int m = m0 + (p & 64) + FM * (p & 15) + ((p & 63) >> 4);
+  unsigned vbase = OOB;
+  unsigned vmask = 0;
+  if (m < a.M) {
+    const int b = (int)a.dTHWo.div((unsigned)m);
+    const int pp = m - b * a.THWo;
+    const int ot = (int)a.dHWo.div((unsigned)pp);
+    const int q = pp - ot * a.HWo;
+    const int oh = (int)a.dWo.div((unsigned)q);
+    const int ow = q - oh * a.Wo;
+    const int it0 = ot * a.st - a.pt, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
+    vbase = (unsigned)(b * a.Cin * a.THW + it0 * a.HW + ih0 * a.W + iw0 + a.pad_off) * 4u;
+    if constexpr (CHECK) vmask = tap_bits(it0, a.kt_, a.T) | (tap_bits(ih0, a.kh_, a.H) << 10) | (tap_bits(iw0, a.kw_, a.W) << 20);
+  }
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) - a.pad_off, 0, a.x_bytes, 0x00020000);
+  const int2* __restrict__ ktab2 = reinterpret_cast<const int2*>(a.ktab + a.Kpad);
+  // ---- B: chunk c of this thread = 16 bytes (8 k) of image row (tid + 256 c) / 4
+  const unsigned short* __restrict__ whi = reinterpret_cast<const unsigned short*>(a.w);
+  const unsigned short* __restrict__ wlo = whi + (size_t)a.Cout * a.Kpad;
+  size_t b_src[NBC];
+  int b_dst[NBC];
+#pragma unroll
+  for (int c = 0; c < NBC; ++c) {
+    const int idx = tid + 256 * c;
+    const int q = idx >> 2, part = idx & 3;             // image row (position), 16-byte part of its 64 bytes
+    constexpr int WN = Cfg::WN;
+    const int ql = q % WN;
+    const int n = n0 + (q / WN) * WN + FN * (ql & 15) + (ql >> 4);
+    b_src[c] = (size_t)n * a.Kpad + part * 8;            // in bf16 elements, + k0 per tile
+    b_dst[c] = q * PITCH + part * 16;
+  }
+
+  float ra[16];
+  uint4 rbh[NBC], rbl[NBC];
+  auto load_tile = [&](int k0) {
+    int ent[32];
+    sload_entries<16>(ktab2, (k0 + khalf * 16) * 8, ent);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      unsigned voff = vbase;
+      if constexpr (CHECK) voff = ((vmask & (unsigned)ent[2 * j + 1]) == (unsigned)ent[2 * j + 1]) ? vbase : OOB;
+      ra[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff, ent[2 * j], 0));
+    }
+#pragma unroll
+    for (int c = 0; c < NBC; ++c) {
+      rbh[c] = *reinterpret_cast<const uint4*>(whi + b_src[c] + k0);
+      rbl[c] = *reinterpret_cast<const uint4*>(wlo + b_src[c] + k0);
+    }
+  };
+  auto store_tile = [&]() {
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split_pair(ra[2 * j], ra[2 * j + 1], h[j], l[j]);
+    const int off = p * PITCH + khalf * 32;
+    *reinterpret_cast<uint4*>(Ah + off) = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4*>(Ah + off + 16) = make_uint4(h[4], h[5], h[6], h[7]);
+    *reinterpret_cast<uint4*>(Al + off) = make_uint4(l[0], l[1], l[2], l[3]);
+    *reinterpret_cast<uint4*>(Al + off + 16) = make_uint4(l[4], l[5], l[6], l[7]);
+#pragma unroll
+    for (int c = 0; c < NBC; ++c) {
+      *reinterpret_cast<uint4*>(Bh + b_dst[c]) = rbh[c];
+      *reinterpret_cast<uint4*>(Bl + b_dst[c]) = rbl[c];
+    }
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lg = lane >> 4;
+  const int a_rd = (wm * Cfg::WM + li) * PITCH + lg * 16;  // + jm * 16 rows
+  const int b_rd = (wn * Cfg::WN + li) * PITCH + lg * 16;  // + jn * 16 rows
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk_all = a.Kpad / BK;
+  const int kt0 = (nk_all * split) / a.splits;
+  const int kt1 = (nk_all * (split + 1)) / a.splits;
+  if (kt0 < kt1) {
+    load_tile(kt0 * BK);
+    store_tile();
+  }
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const bool more = kt + 1 < kt1;
+    if (more) load_tile((kt + 1) * BK);  // in flight under this tile's MFMAs
+    bf16x8 bh[FN], bl[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bh + b_rd + j * 16 * PITCH));
+      bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bl + b_rd + j * 16 * PITCH));
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Ah + a_rd + i * 16 * PITCH));
+      const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Al + a_rd + i * 16 * PITCH));
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();  // every wave has read this tile
+    if (more) store_tile();
+    __syncthreads();
+  }
+  igemm_epilogue<BM, BN, BK>(a, acc, reinterpret_cast<float*>(smem), split, m0, n0, wave, lane);
+}
+
+// fp32 weights (Cout, K) (torch layout: K = (ci, dt, dh, dw) contiguous) -> [2][Cout][Kpad] bf16: hi image, lo image
+__global__ void pack_weight_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int Cout, int K, int Kpad) {
+  const long long total = (long long)Cout * Kpad;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int n = (int)(i / Kpad), k = (int)(i - (long long)n * Kpad);
+    const float v = k < K ? w[(size_t)n * K + k] : 0.f;
+    unsigned h, l;
+    split_pair(v, 0.f, h, l);
+    out[i] = (unsigned short)(h & 0xFFFFu);
+    out[total + i] = (unsigned short)(l & 0xFFFFu);
+  }
+}
+
 // y = act(sum_s slab[s] * scale[c] + shift[c] (+ res)), slabs in NCDHW like y
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ scale,
                                      const float* __restrict__ shift, const float* __restrict__ res,
@@ -939,6 +1125,18 @@ extern "C" int advhip_conv3d_pack_weight_f32(const advhip_conv3d_desc* d, const 
   return check_launch("pack_weight");
 }
 
+extern "C" int advhip_conv3d_pack_weight_bf16x3(const advhip_conv3d_desc* d, const float* w, void* w_split, void* stream) {
+  if (int rc = validate(d)) return rc;
+  ADVHIP_REQUIRE(w && w_split, "pack_weight_bf16x3: null pointer");
+  const int K = d->Cin * d->kt * d->kh * d->kw;
+  const int Kpad = (K + 31) / 32 * 32;
+  const long long total = (long long)Kpad * d->Cout;
+  const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(pack_weight_bf16x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w,
+                     reinterpret_cast<unsigned short*>(w_split), d->Cout, K, Kpad);
+  return check_launch("pack_weight_bf16x3");
+}
+
 extern "C" int advhip_conv3d_build_ktab(const advhip_conv3d_desc* d, int32_t* ktab, void* stream) {
   if (int rc = validate(d)) return rc;
   ADVHIP_REQUIRE(ktab, "build_ktab: null pointer");
@@ -965,6 +1163,7 @@ struct Choice {
 };
 
 static void tile_of(int algo, int* BM, int* BN, int* BK) {
+  if (algo >= ADVHIP_ALGO_BF16X3_BASE) algo -= ADVHIP_ALGO_BF16X3_BASE;
   if (algo >= ADVHIP_ALGO_DMA4_BASE) algo -= ADVHIP_ALGO_DMA4_BASE;
   if (algo >= ADVHIP_ALGO_DMA_BASE) algo -= ADVHIP_ALGO_DMA_BASE;
   if (algo >= ADVHIP_ALGO_FAST_BASE) algo -= ADVHIP_ALGO_FAST_BASE;
@@ -1062,7 +1261,8 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
   int BM, BN, BK;
   tile_of(c.algo, &BM, &BN, &BK);
   const bool fast = c.algo >= ADVHIP_ALGO_FAST_BASE;  // includes the LDS-DMA ids
-  const int base_algo = c.algo >= ADVHIP_ALGO_DMA4_BASE ? c.algo - ADVHIP_ALGO_DMA4_BASE
+  const int base_algo = c.algo >= ADVHIP_ALGO_BF16X3_BASE ? c.algo - ADVHIP_ALGO_BF16X3_BASE
+                        : c.algo >= ADVHIP_ALGO_DMA4_BASE ? c.algo - ADVHIP_ALGO_DMA4_BASE
                         : c.algo >= ADVHIP_ALGO_DMA_BASE ? c.algo - ADVHIP_ALGO_DMA_BASE
                         : (fast ? c.algo - ADVHIP_ALGO_FAST_BASE : c.algo);
   ADVHIP_REQUIRE(base_algo >= ADVHIP_ALGO_IGEMM_128x128 && base_algo <= ADVHIP_ALGO_IGEMM_64x128x32, "conv3d: unknown algo %d", c.algo);
@@ -1098,7 +1298,7 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
   a.dTilesN = FastDiv::make((unsigned)a.tiles_n);
   a.dSplits = FastDiv::make((unsigned)c.splits);
   dim3 grid((unsigned)(a.tiles_m * a.tiles_n * c.splits));
-  if (c.algo >= ADVHIP_ALGO_DMA_BASE) {
+  if (c.algo >= ADVHIP_ALGO_DMA_BASE && c.algo < ADVHIP_ALGO_BF16X3_BASE) {
     // persistent launch of the LDS-DMA kernel: at most `slots` workgroups per CU stay resident and
     // loop over the work items (ADVHIP_PERSISTENT_SLOTS, 0 = one workgroup per item)
     static const int slots = getenv("ADVHIP_PERSISTENT_SLOTS") ? atoi(getenv("ADVHIP_PERSISTENT_SLOTS")) : 0;
@@ -1125,7 +1325,14 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
     if (nocheck) hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, false, 4>), grid, dim3(256), 0, st, a);  \
     else hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, true, 4>), grid, dim3(256), 0, st, a);           \
     break;
+#define ADVHIP_BF16X3_CASE(ID, BN_)                                                                               \
+  case ADVHIP_ALGO_BF16X3_BASE + ID:                                                                               \
+    if (nocheck) hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BN_, false>), grid, dim3(256), 0, st, a);          \
+    else hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BN_, true>), grid, dim3(256), 0, st, a);                   \
+    break;
   switch (c.algo) {
+    ADVHIP_BF16X3_CASE(ADVHIP_ALGO_IGEMM_128x128x32, 128)
+    ADVHIP_BF16X3_CASE(ADVHIP_ALGO_IGEMM_128x64x32, 64)
     ADVHIP_DMA4_CASE(ADVHIP_ALGO_IGEMM_128x64, 128, 64, 16)
     ADVHIP_DMA4_CASE(ADVHIP_ALGO_IGEMM_64x64, 64, 64, 16)
     ADVHIP_DMA4_CASE(ADVHIP_ALGO_IGEMM_64x128, 64, 128, 16)

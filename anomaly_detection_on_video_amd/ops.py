@@ -5,6 +5,8 @@ Every function here REQUIRES CUDA tensors and the built HIP extension; none has 
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from dataclasses import dataclass, field
 from typing import Dict, Optional, Sequence, Tuple
@@ -43,6 +45,8 @@ class PackedConv:
     algo: int = _lib.ALGO_AUTO
     name: str = ""
     splits: int = 0  # 0 = library heuristic
+    weight: Optional[torch.Tensor] = None   # the torch-layout fp32 weights (a reference, not a copy)
+    w_split: Optional[torch.Tensor] = None  # bf16 hi/lo images for the opt-in split-bf16 kernels, packed on first use
     # (B,T,H,W) -> (algo, splits) resolved from the measured table (tuned.py)
     choices: Dict[Tuple[int, int, int, int], Tuple[int, int]] = field(default_factory=dict)
 
@@ -59,7 +63,10 @@ class PackedConv:
             if ch is None:
                 from . import tuned
 
-                ch = self.choices[(B, T, H, W)] = tuned.lookup(self.key(B, T, H, W), (self.algo, self.splits))
+                ch = tuned.lookup(self.key(B, T, H, W), (self.algo, self.splits))
+                if ARITH == "bf16x3":  # opt-in: every conv on the split-bf16 kernels (128x64x32 tile fits every Cout of the net)
+                    ch = (_lib.ALGO_BF16X3_BASE + 6, 1)
+                self.choices[(B, T, H, W)] = ch
             algo, splits = ch
         return ConvDesc(B, self.cin, T, H, W, self.cout, kt, kh, kw, st, sh, sw, pt, ph, pw, int(relu),
                         self.algo if algo is None else algo, self.splits if splits is None else splits)
@@ -90,6 +97,17 @@ def _build_ktab(pc: PackedConv, thw: Tuple[int, int, int]) -> torch.Tensor:
     return ktab
 
 
+def split_weight(pc: PackedConv) -> torch.Tensor:
+    """The bf16 hi/lo weight images of `pc` (uint16 [2][Cout][Kpad]) for the ADVHIP_ALGO_BF16X3_* kernels."""
+    if pc.w_split is None:
+        kt, kh, kw = pc.kernel
+        d = pc.desc(1, kt, kh, kw, relu=False, algo=0, splits=1)
+        out = torch.empty((2, pc.cout, pc.w_packed.shape[0]), device=pc.weight.device, dtype=torch.int16)
+        check(_lib.load().advhip_conv3d_pack_weight_bf16x3(C.byref(d), ptr(pc.weight), ptr(out), stream()), "pack_weight_bf16x3")
+        pc.w_split = out
+    return pc.w_split
+
+
 def ensure_ktab(pc: PackedConv, thw: Tuple[int, int, int]) -> torch.Tensor:
     """The gather table of `pc` for input dims (T,H,W), built on the current stream on first use."""
     ktab = pc.ktabs.get(thw)
@@ -110,8 +128,12 @@ def pack_conv(weight: torch.Tensor, gamma, beta, mean, var, eps: float, stride, 
     wp = torch.empty((_packed_rows(d), cout), device=weight.device, dtype=torch.float32)
     check(_lib.load().advhip_conv3d_pack_weight_f32(C.byref(d), ptr(weight), ptr(wp), stream()), "pack_weight")
     pc.w_packed = wp
+    pc.weight = weight
     return pc
 
+
+# ADV_ARITH=bf16x3: opt-in split-bf16 arithmetic for every conv (see include/advhip.h ADVHIP_ALGO_BF16X3_BASE); default: exact fp32
+ARITH = os.environ.get("ADV_ARITH", "f32")
 
 _WORKSPACES: Dict[Tuple[torch.device, int], torch.Tensor] = {}
 
@@ -150,7 +172,10 @@ def conv3d_bn_act(x: torch.Tensor, pc: PackedConv, relu: bool = True, residual: 
     if need < 0:
         check(int(need), f"conv3d_workspace_bytes[{pc.name}]")
     ws = workspace(x.device, need)
-    check(lib.advhip_conv3d_bn_act_f32(C.byref(d), ptr(x), ptr(pc.w_packed), ptr(ktab), ptr(pc.scale), ptr(pc.shift),
+    w = pc.w_packed
+    if d.algo >= _lib.ALGO_BF16X3_BASE:
+        w = split_weight(pc)
+    check(lib.advhip_conv3d_bn_act_f32(C.byref(d), ptr(x), ptr(w), ptr(ktab), ptr(pc.scale), ptr(pc.shift),
                                        ptr(residual), ptr(y), ptr(ws), need, stream()), f"conv3d[{pc.name}]")
     return y
 

@@ -48,6 +48,11 @@ extern "C" {
 #define ADVHIP_ALGO_DMA_BASE 64
 /* + tile id 2..4: the same with a 4-deep ring (three k-tiles in flight) */
 #define ADVHIP_ALGO_DMA4_BASE 96
+/* + tile id 5 (128x128x32) or 6 (128x64x32): OPT-IN split-bf16 arithmetic -- every fp32 operand as two bf16 terms,
+ * three bf16 MFMAs (hi*hi + hi*lo + lo*hi) accumulated in fp32: 3/16 of the fp32 MFMA cycles, agreement with the
+ * fp32 kernels ~1e-5 relative (inside the 1e-3 contract, not bit-comparable).  Takes the weights from
+ * advhip_conv3d_pack_weight_bf16x3 instead of advhip_conv3d_pack_weight_f32.  Never chosen by ADVHIP_ALGO_AUTO. */
+#define ADVHIP_ALGO_BF16X3_BASE 128
 
 typedef struct advhip_conv3d_desc {
   int32_t B, Cin, T, H, W;    /* input  (B, Cin, T, H, W) */
@@ -77,6 +82,10 @@ int advhip_conv3d_packed_rows(const advhip_conv3d_desc* d);
  * load-time analogue of model.load_state_dict (src/i3d.py:356-359). */
 int advhip_conv3d_pack_weight_f32(const advhip_conv3d_desc* d, const float* w, float* w_packed,
                                   void* stream);
+
+/* Split torch-layout fp32 weights into the bf16 images of the ADVHIP_ALGO_BF16X3_* kernels:
+ * w_split = uint16[2][Cout][Kpad] (hi image, then lo image; k contiguous, zero above K); 4*Cout*Kpad bytes. */
+int advhip_conv3d_pack_weight_bf16x3(const advhip_conv3d_desc* d, const float* w, void* w_split, void* stream);
 
 /* Per-row gather table for one input size (d->T, d->H, d->W):
  * ktab[k] = {input element offset of tap k relative to the window origin, dt, dh, dw}; rows

@@ -110,6 +110,36 @@ def test_conv_bn_act_vs_oracle(case, algo):
         assert e < TOL
 
 
+BF16X3_TOL = 1e-4  # split-bf16 arithmetic (hi*hi + hi*lo + lo*hi): ~2^-16 per product; the contract is TOL = 1e-3
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+@pytest.mark.parametrize("algo,splits", [(133, 1), (134, 1), (134, 2), (133, 3)], ids=["x3_128x128", "x3_128x64", "x3_128x64_s2", "x3_128x128_s3"])
+def test_conv_split_bf16_vs_oracle(case, algo, splits):
+    """The opt-in split-bf16 kernels (ADVHIP_ALGO_BF16X3_*) against the fp32 oracle: not bit-comparable with an fp32
+    FMA chain by construction, so the bar is 1e-4 of the output range (10x inside the 1e-3 contract), on every conv
+    shape of the net and the edge cases, with and without residual / ReLU / split-K; deterministic run to run."""
+    from anomaly_detection_on_video_amd import ops
+    from oracle import i3d_oracle
+
+    name, cin, cout, k, s, p, bthw = case
+    if algo == 133 and cout % 128:
+        pytest.skip("Cout not a multiple of the 128-wide N tile")
+    x, wt, g, be, mu, var, res = _conv_case(*case)
+    dev = _dev()
+    pc = ops.pack_conv(wt.to(dev), g.to(dev), be.to(dev), mu.to(dev), var.to(dev), 1e-5, s, p, name=name)
+    if splits > pc.w_packed.shape[0] // 32:
+        pytest.skip("fewer k-tiles than splits")
+    for use_res, relu in ((False, True), (True, False)):
+        ref = i3d_oracle.conv_bn_act(x, wt, g, be, mu, var, s, p, res if use_res else None, relu)
+        out = ops.conv3d_bn_act(x.to(dev), pc, relu=relu, residual=res.to(dev) if use_res else None, algo=algo, splits=splits)
+        again = ops.conv3d_bn_act(x.to(dev), pc, relu=relu, residual=res.to(dev) if use_res else None, algo=algo, splits=splits)
+        assert out.shape == ref.shape
+        e = rel_err(out.cpu(), ref)
+        assert e < BF16X3_TOL, f"{name} algo={algo} splits={splits} res={use_res} relu={relu}: rel err {e:.3e}"
+        assert torch.equal(out, again)
+
+
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0] in ("l2.conv2", "l3.conv1.t3", "l4.conv2", "edge.7x7", "l1.conv3", "edge.odd")],
                          ids=lambda c: c[0])
 @pytest.mark.parametrize("algo,splits", [(3, 2), (1, 3), (7, 4), (6, 2), (0, 0), (35, 2), (36, 3), (39, 4), (67, 2), (68, 3), (71, 4), (99, 3), (100, 2)])
@@ -243,6 +273,27 @@ def test_fullnet_batch_independence_and_determinism(model):
     y_one = model(x[3:4].contiguous()).reshape(1, 2048)
     assert rel_err(y_one.cpu(), y_all[3:4].cpu()) < 1e-5
     assert torch.isfinite(y_all).all()
+
+
+def test_fullnet_split_bf16_vs_reference_golden(monkeypatch):
+    """Opt-in arithmetic (ADV_ARITH=bf16x3): all 53 convs on the split-bf16 kernels.  Features agree with the
+    reference's fp32 goldens to a few 1e-5 of the feature range -- inside the 1e-3 contract, far from the 2e-7 of the
+    default fp32 path, which is why it is not the default."""
+    from anomaly_detection_on_video_amd import ops
+    from anomaly_detection_on_video_amd.i3d import I3Res50
+
+    monkeypatch.setattr(ops, "ARITH", "bf16x3")
+    m = I3Res50(use_nl=False)
+    m.load_state_dict(synth_i3d_state_dict(), strict=True)
+    m = m.eval().to(_dev())
+    g = np.load(os.path.join(GOLDEN, "i3d_fullnet.npz"))
+    x = synth_input((2, 3, 16, 224, 224), 0).to(_dev())
+    y = m(x).reshape(2, 2048)
+    assert all(c.choices and all(a >= 128 for a, _s in c.choices.values()) for c in m.packed_convs())
+    e = rel_err(y.cpu(), g["feat_seed0"])
+    assert e < 3e-4, f"split-bf16 whole net: rel err {e:.3e}"
+    assert e < TOL
+    assert torch.equal(y, m(x).reshape(2, 2048))
 
 
 def test_batch_split_over_streams(model):
