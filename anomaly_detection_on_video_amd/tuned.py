@@ -17,6 +17,11 @@ def table() -> Dict[str, Tuple[int, int]]:
         if os.environ.get("ADV_NO_TUNED") != "1" and os.path.exists(_PATH):
             with open(_PATH) as f:
                 _TABLE = {k: (int(v[0]), int(v[1])) for k, v in json.load(f).items()}
+            # ADV_ARITH=mixed (opt-in): shapes where a split-bf16 kernel measured faster override the fp32 choice
+            mixed = os.path.join(os.path.dirname(_PATH), "gfx950_mixed.json")
+            if os.environ.get("ADV_ARITH") == "mixed" and os.path.exists(mixed):
+                with open(mixed) as f:
+                    _TABLE.update({k: (int(v[0]), int(v[1])) for k, v in json.load(f).items()})
     return _TABLE
 
 

@@ -296,6 +296,35 @@ def test_fullnet_split_bf16_vs_reference_golden(monkeypatch):
     assert torch.equal(y, m(x).reshape(2, 2048))
 
 
+def test_fullnet_mixed_arithmetic_table():
+    """ADV_ARITH=mixed overlays tuned/gfx950_mixed.json (shapes where a split-bf16 kernel measured faster in the
+    stream) on the fp32 table.  Checked here without the env var: the overlay's B=32 choices applied to a fresh model
+    at batch 2 keys, whole-net features within 3e-4 of the reference goldens."""
+    import json
+    from anomaly_detection_on_video_amd.i3d import I3Res50
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "anomaly_detection_on_video_amd", "tuned", "gfx950_mixed.json")
+    overlay = {tuple(int(v) for v in k.split(",")[:11]): tuple(v) for k, v in json.load(open(path)).items()}
+    assert overlay and all(a >= 128 for a, _s in overlay.values())
+    m = I3Res50(use_nl=False)
+    m.load_state_dict(synth_i3d_state_dict(), strict=True)
+    m = m.eval().to(_dev())
+    m.prepare()
+    x = synth_input((2, 3, 16, 224, 224), 1).to(_dev())
+    m(x)  # resolves every conv's choice for these dims
+    moved = 0
+    for c in m.packed_convs():
+        sig = (c.cin, c.cout, *c.kernel, *c.stride, *c.padding)
+        if sig in overlay:
+            for key in list(c.choices):
+                c.choices[key] = (overlay[sig][0], 1)
+            moved += 1
+    assert moved >= 10
+    g = np.load(os.path.join(GOLDEN, "i3d_fullnet.npz"))
+    e = rel_err(m(x).reshape(2, 2048).cpu(), g["feat_seed1"])
+    assert e < 3e-4, f"mixed arithmetic whole net: rel err {e:.3e}"
+
+
 def test_batch_split_over_streams(model):
     """The default forward cuts a batch of >= 8 crop-clips into two parts on two HIP streams
     (I3Res50._run_streams).  Same features as the one-stream forward (fp32 summation order may differ

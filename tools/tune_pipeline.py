@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                   "anomaly_detection_on_video_amd", "tuned", "gfx950.json"))
     ap.add_argument("--sweeps", type=int, default=1)
+    ap.add_argument("--candidates", default="", help="comma list of algo:splits overriding the candidate list, e.g. 133:1,134:1,134:2")
+    ap.add_argument("--only-changes", action="store_true", help="write only the entries this run changed (an overlay table)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     bb = I3Res50()
@@ -95,14 +97,16 @@ def main():
 
     base = measure()
     print(f"{len(groups)} distinct conv shapes, stream step {base:.4f} ms", flush=True)
-    table = json.load(open(args.out)) if os.path.exists(args.out) else {}
+    table = json.load(open(args.out)) if os.path.exists(args.out) and not args.only_changes else {}
     for sweep in range(args.sweeps):
         changed = 0
         for key in groups:
             pc, d = groups[key][0]
             cur = current(key)
             cands = [c for c in (ranked.get(key) or FIXED) if c != cur]
-            if not ranked.get(key) and cur[1] > 1:
+            if args.candidates:
+                cands = [tuple(int(v) for v in c.split(":")) for c in args.candidates.split(",")]
+            elif not ranked.get(key) and cur[1] > 1:
                 cands += [(a, cur[1]) for a in (67, 68, 71, 99, 100) if (a, cur[1]) != cur]
             best_c, best_t = cur, base
             for a, s in cands:
