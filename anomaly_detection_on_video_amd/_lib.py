@@ -34,10 +34,14 @@ ALGO_DMA4_BASE = 96  # + tile id 2..4: 4-deep ring
 DMA4_ALGOS = tuple(ALGO_DMA4_BASE + a for a in (2, 3, 4))
 ALGO_BF16X3_BASE = 128  # + tile id 5 (128x128x32) / 6 (128x64x32): opt-in split-bf16 arithmetic (3 bf16 MFMAs per fragment)
 BF16X3_ALGOS = tuple(ALGO_BF16X3_BASE + a for a in (5, 6))
+ALGO_DMA2_BASE = 160  # + tile id: LDS-DMA kernel, 2-deep ring (less LDS, more resident workgroups)
+DMA2_ALGOS = tuple(ALGO_DMA2_BASE + a for a in (1, 2, 3, 4, 6, 7, 8))
 
 
 def algo_tile(algo: int):
     """(BM, BN, BK) of an implicit-GEMM algorithm id."""
+    if algo >= ALGO_DMA2_BASE:
+        algo -= ALGO_DMA2_BASE
     if algo >= ALGO_BF16X3_BASE:
         algo -= ALGO_BF16X3_BASE
     if algo >= ALGO_DMA4_BASE:

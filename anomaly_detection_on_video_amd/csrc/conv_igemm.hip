@@ -628,7 +628,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   using Cfg = IgemmCfg<BM, BN, BK>;
   using D = DmaCfg<BM, BN, BK>;
   constexpr int FM = Cfg::FM, FN = Cfg::FN, KR = D::KR, LA = D::LA, LB = D::LB, KS = BK / 4;
-  static_assert(NS == 3 || NS == 4, "ring depth");
+  static_assert(NS == 2 || NS == 3 || NS == 4, "ring depth");
   static_assert(LB >= 1 && LA >= 1 && (NS - 2) * (LA + LB) <= 63, "tile / vmcnt budget");
   constexpr unsigned OOB = 0xFFFFFF00u;
   constexpr int RING = NS * D::STAGE;
@@ -796,7 +796,8 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   for (int kt = kt0; kt < kt1; ++kt) {
     // tile kt has landed once only the loads of the younger tiles in flight (<= NS-2) are outstanding
     const int younger = kt1 - 1 - kt;
-    if (NS == 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LAI + LBI)) : "memory");
+    if (NS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the only tile in flight is tile kt
+    else if (NS == 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LAI + LBI)) : "memory");
     else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LAI + LBI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");  // all waves' parts of tile kt are in LDS; stage (kt-1)%NS is free
@@ -1163,6 +1164,7 @@ struct Choice {
 };
 
 static void tile_of(int algo, int* BM, int* BN, int* BK) {
+  if (algo >= ADVHIP_ALGO_DMA2_BASE) algo -= ADVHIP_ALGO_DMA2_BASE;
   if (algo >= ADVHIP_ALGO_BF16X3_BASE) algo -= ADVHIP_ALGO_BF16X3_BASE;
   if (algo >= ADVHIP_ALGO_DMA4_BASE) algo -= ADVHIP_ALGO_DMA4_BASE;
   if (algo >= ADVHIP_ALGO_DMA_BASE) algo -= ADVHIP_ALGO_DMA_BASE;
@@ -1260,8 +1262,9 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
   const Choice c = choose(d, M, g.Kpad);
   int BM, BN, BK;
   tile_of(c.algo, &BM, &BN, &BK);
-  const bool fast = c.algo >= ADVHIP_ALGO_FAST_BASE;  // includes the LDS-DMA ids
-  const int base_algo = c.algo >= ADVHIP_ALGO_BF16X3_BASE ? c.algo - ADVHIP_ALGO_BF16X3_BASE
+  const bool fast = c.algo >= ADVHIP_ALGO_FAST_BASE;  // includes the LDS-DMA and split-bf16 ids
+  const int base_algo = c.algo >= ADVHIP_ALGO_DMA2_BASE ? c.algo - ADVHIP_ALGO_DMA2_BASE
+                        : c.algo >= ADVHIP_ALGO_BF16X3_BASE ? c.algo - ADVHIP_ALGO_BF16X3_BASE
                         : c.algo >= ADVHIP_ALGO_DMA4_BASE ? c.algo - ADVHIP_ALGO_DMA4_BASE
                         : c.algo >= ADVHIP_ALGO_DMA_BASE ? c.algo - ADVHIP_ALGO_DMA_BASE
                         : (fast ? c.algo - ADVHIP_ALGO_FAST_BASE : c.algo);
@@ -1298,7 +1301,7 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
   a.dTilesN = FastDiv::make((unsigned)a.tiles_n);
   a.dSplits = FastDiv::make((unsigned)c.splits);
   dim3 grid((unsigned)(a.tiles_m * a.tiles_n * c.splits));
-  if (c.algo >= ADVHIP_ALGO_DMA_BASE && c.algo < ADVHIP_ALGO_BF16X3_BASE) {
+  if ((c.algo >= ADVHIP_ALGO_DMA_BASE && c.algo < ADVHIP_ALGO_BF16X3_BASE) || c.algo >= ADVHIP_ALGO_DMA2_BASE) {
     // persistent launch of the LDS-DMA kernel: at most `slots` workgroups per CU stay resident and
     // loop over the work items (ADVHIP_PERSISTENT_SLOTS, 0 = one workgroup per item)
     static const int slots = getenv("ADVHIP_PERSISTENT_SLOTS") ? atoi(getenv("ADVHIP_PERSISTENT_SLOTS")) : 0;
@@ -1325,12 +1328,24 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
     if (nocheck) hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, false, 4>), grid, dim3(256), 0, st, a);  \
     else hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, true, 4>), grid, dim3(256), 0, st, a);           \
     break;
+#define ADVHIP_DMA2_CASE(ID, BM_, BN_, BK_)                                                                          \
+  case ADVHIP_ALGO_DMA2_BASE + ID:                                                                                   \
+    if (nocheck) hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, false, 2>), grid, dim3(256), 0, st, a);  \
+    else hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, true, 2>), grid, dim3(256), 0, st, a);           \
+    break;
 #define ADVHIP_BF16X3_CASE(ID, BN_)                                                                               \
   case ADVHIP_ALGO_BF16X3_BASE + ID:                                                                               \
     if (nocheck) hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BN_, false>), grid, dim3(256), 0, st, a);          \
     else hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BN_, true>), grid, dim3(256), 0, st, a);                   \
     break;
   switch (c.algo) {
+    ADVHIP_DMA2_CASE(ADVHIP_ALGO_IGEMM_128x128, 128, 128, 16)
+    ADVHIP_DMA2_CASE(ADVHIP_ALGO_IGEMM_128x64, 128, 64, 16)
+    ADVHIP_DMA2_CASE(ADVHIP_ALGO_IGEMM_64x64, 64, 64, 16)
+    ADVHIP_DMA2_CASE(ADVHIP_ALGO_IGEMM_64x128, 64, 128, 16)
+    ADVHIP_DMA2_CASE(ADVHIP_ALGO_IGEMM_128x64x32, 128, 64, 32)
+    ADVHIP_DMA2_CASE(ADVHIP_ALGO_IGEMM_64x64x32, 64, 64, 32)
+    ADVHIP_DMA2_CASE(ADVHIP_ALGO_IGEMM_64x128x32, 64, 128, 32)
     ADVHIP_BF16X3_CASE(ADVHIP_ALGO_IGEMM_128x128x32, 128)
     ADVHIP_BF16X3_CASE(ADVHIP_ALGO_IGEMM_128x64x32, 64)
     ADVHIP_DMA4_CASE(ADVHIP_ALGO_IGEMM_128x64, 128, 64, 16)

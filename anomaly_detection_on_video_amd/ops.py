@@ -173,7 +173,7 @@ def conv3d_bn_act(x: torch.Tensor, pc: PackedConv, relu: bool = True, residual: 
         check(int(need), f"conv3d_workspace_bytes[{pc.name}]")
     ws = workspace(x.device, need)
     w = pc.w_packed
-    if d.algo >= _lib.ALGO_BF16X3_BASE:
+    if _lib.ALGO_BF16X3_BASE <= d.algo < _lib.ALGO_DMA2_BASE:
         w = split_weight(pc)
     check(lib.advhip_conv3d_bn_act_f32(C.byref(d), ptr(x), ptr(w), ptr(ktab), ptr(pc.scale), ptr(pc.shift),
                                        ptr(residual), ptr(y), ptr(ws), need, stream()), f"conv3d[{pc.name}]")

@@ -53,6 +53,9 @@ extern "C" {
  * fp32 kernels ~1e-5 relative (inside the 1e-3 contract, not bit-comparable).  Takes the weights from
  * advhip_conv3d_pack_weight_bf16x3 instead of advhip_conv3d_pack_weight_f32.  Never chosen by ADVHIP_ALGO_AUTO. */
 #define ADVHIP_ALGO_BF16X3_BASE 128
+/* + tile id 1..4, 6..8: the LDS-DMA kernel with a 2-deep ring (one k-tile in flight): 16 KiB of LDS per 64x64x16
+ * workgroup instead of 24 -> 8 resident workgroups per CU instead of 6 */
+#define ADVHIP_ALGO_DMA2_BASE 160
 
 typedef struct advhip_conv3d_desc {
   int32_t B, Cin, T, H, W;    /* input  (B, Cin, T, H, W) */

@@ -68,7 +68,7 @@ def main():
             kpad = pc.w_packed.shape[0]
             cands = []
             taps = pc.kernel[0] * pc.kernel[1] * pc.kernel[2]
-            for algo in ((3,) if args.quick else _lib.IGEMM_ALGOS) + ((35,) if args.quick else _lib.FAST_ALGOS) + _lib.DMA_ALGOS + _lib.DMA4_ALGOS:
+            for algo in ((3,) if args.quick else _lib.IGEMM_ALGOS) + ((35,) if args.quick else _lib.FAST_ALGOS) + _lib.DMA_ALGOS + _lib.DMA4_ALGOS + _lib.DMA2_ALGOS:
                 bm, bn, bk = _lib.algo_tile(algo)
                 if pc.cout % bn:
                     continue
