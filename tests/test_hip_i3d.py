@@ -327,30 +327,30 @@ def test_fullnet_mixed_arithmetic_table():
 
 
 def test_batch_split_over_streams(model):
-    """The default forward cuts a batch of >= 8 crop-clips into two parts on two HIP streams
+    """The default forward cuts a batch of >= 16 crop-clips into two parts on two HIP streams
     (I3Res50._run_streams).  Same features as the one-stream forward (fp32 summation order may differ
     with the tile choice per part), bit-identical run to run, also on input dims whose gather tables
     did not exist before the fork (they must be built ahead of it), and for an odd batch."""
     from anomaly_detection_on_video_amd.i3d import I3Res50
 
-    assert model._n_streams(32) == 2 and model._n_streams(8) == 2 and model._n_streams(7) == 1
-    x = synth_input((9, 3, 16, 224, 224), 5).to(_dev())
-    y2 = model(x).reshape(9, 2048)
-    assert torch.equal(y2, model(x).reshape(9, 2048))
+    assert model._n_streams(32) == 2 and model._n_streams(16) == 2 and model._n_streams(15) == 1
+    x = synth_input((17, 3, 16, 112, 112), 5).to(_dev())
+    y2 = model(x).reshape(17, 2048)
+    assert torch.equal(y2, model(x).reshape(17, 2048))
     keep = model.streams
     try:
         model.streams = 1
-        y1 = model(x).reshape(9, 2048)
+        y1 = model(x).reshape(17, 2048)
     finally:
         model.streams = keep
     assert rel_err(y2.cpu(), y1.cpu()) < 1e-5
     fresh = I3Res50(use_nl=False)
     fresh.load_state_dict(synth_i3d_state_dict(), strict=True)
     fresh = fresh.eval().to(_dev())
-    xs = synth_input((8, 3, 8, 96, 80), 6).to(_dev())  # dims no other test uses: tables are built inside this call
-    ya = fresh(xs).reshape(8, 2048)
+    xs = synth_input((16, 3, 8, 96, 80), 6).to(_dev())  # dims no other test uses: tables are built inside this call
+    ya = fresh(xs).reshape(16, 2048)
     fresh.streams = 1
-    yb = fresh(xs).reshape(8, 2048)
+    yb = fresh(xs).reshape(16, 2048)
     assert rel_err(ya.cpu(), yb.cpu()) < 1e-5
 
 
