@@ -56,6 +56,8 @@ def run_chunks_on_lanes(model, chunks, lanes: Optional[int] = None) -> torch.Ten
     while len(pool) < lanes:
         pool.append(torch.cuda.Stream(device=dev))
     cur = torch.cuda.current_stream(dev)
+    if hasattr(model, "ensure_tables"):
+        model.ensure_tables(tuple(chunks[0].shape[2:]))  # lazily built state: before the lanes fork
     ready = torch.cuda.Event()
     ready.record(cur)
     outs, inner = [], getattr(model, "streams", 1)

@@ -201,6 +201,22 @@ class I3Res50(nn.Module):
                 mark()
         return x
 
+    def ensure_tables(self, thw: Tuple[int, int, int]) -> None:
+        """Pack the weights and build every conv's gather table for clips of dims (T,H,W) on the CURRENT stream.
+        Both happen lazily on whatever stream first needs them; a caller that is about to run forwards on other
+        streams (stream parts, pipeline lanes) calls this first and orders those streams after it."""
+        self.prepare()
+        dims = tuple(thw)
+        for u in self._plan:
+            if u.kind == "maxpool":
+                dims = ops.conv_out_dims(dims, u.kernel, u.stride, (0, 0, 0))
+            elif u.kind in ("stem", "bottleneck"):
+                if u.kind == "bottleneck" and u.convs[3] is not None:
+                    ops.ensure_ktab(u.convs[3], dims)  # the downsample branch reads the unit's input
+                for c in u.convs[:3]:
+                    ops.ensure_ktab(c, dims)
+                    dims = ops.conv_out_dims(dims, c.kernel, c.stride, c.padding)
+
     def _n_streams(self, batch: int) -> int:
         """Streams a forward of `batch` crop-clips is spread over (each part keeps >= MIN_PART clips)."""
         return max(1, min(self.streams, batch // self.MIN_PART))
@@ -214,17 +230,7 @@ class I3Res50(nn.Module):
         with the final ones."""
         B = x.shape[0]
         bounds = [(B * i) // n for i in range(n + 1)]
-        # gather tables are built lazily on the launching stream: make sure they exist before the fork
-        dims = tuple(x.shape[2:])
-        for u in self._plan:
-            if u.kind == "maxpool":
-                dims = ops.conv_out_dims(dims, u.kernel, u.stride, (0, 0, 0))
-            elif u.kind in ("stem", "bottleneck"):
-                if u.kind == "bottleneck" and u.convs[3] is not None:
-                    ops.ensure_ktab(u.convs[3], dims)  # the downsample branch reads the unit's input
-                for c in u.convs[:3]:
-                    ops.ensure_ktab(c, dims)
-                    dims = ops.conv_out_dims(dims, c.kernel, c.stride, c.padding)
+        self.ensure_tables(tuple(x.shape[2:]))
         main = torch.cuda.current_stream(x.device)
         while len(self._side_streams) < n - 1:
             self._side_streams.append(torch.cuda.Stream(device=x.device))

@@ -45,6 +45,8 @@ class ExtractScoreStream:
         self._lane_streams: List[torch.cuda.Stream] = []
         self._lane_next = 0
         self._ordered: Optional[torch.cuda.Event] = None  # end of the previous step's gather + ingest
+        self._table_dims: set = set()                      # clip dims whose gather tables exist
+        self._tables_built: Optional[torch.cuda.Event] = None
 
     @torch.no_grad()
     def step(self, local_clips: torch.Tensor) -> Tuple[torch.Tensor, List[Tuple[int, torch.Tensor]]]:
@@ -75,12 +77,25 @@ class ExtractScoreStream:
             self._lane_streams.append(torch.cuda.Stream(device=dev))
         lane = self._lane_streams[self._lane_next]
         self._lane_next = (self._lane_next + 1) % self.lanes
+        # packed weights and gather tables are created lazily on the stream that first needs them: create them
+        # before the lanes fork (dims known), or on this lane with an event every later lane step waits for
+        tables = getattr(self.backbone, "ensure_tables", None)
+        if prepare is None and tables is not None and tuple(local_clips.shape[2:]) not in self._table_dims:
+            tables(tuple(local_clips.shape[2:]))
+            self._table_dims.add(tuple(local_clips.shape[2:]))
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))
         with torch.cuda.stream(lane):
             lane.wait_event(ready)
+            if self._tables_built is not None:
+                lane.wait_event(self._tables_built)
             if prepare is not None:
                 local_clips = prepare(local_clips)
+                if tables is not None and tuple(local_clips.shape[2:]) not in self._table_dims:
+                    tables(tuple(local_clips.shape[2:]))
+                    self._table_dims.add(tuple(local_clips.shape[2:]))
+                    self._tables_built = torch.cuda.Event()
+                    self._tables_built.record(lane)
             else:
                 local_clips.record_stream(lane)
             inner = getattr(self.backbone, "streams", 1)
