@@ -97,8 +97,8 @@ def cpu_baseline(budget_s: float = 12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=32, help="crop-clips per GPU per step (BASELINE config 2: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--h2d", action="store_true", help="also time a PCIe-inclusive variant (host fp32 input each step)")
