@@ -81,7 +81,9 @@ SIGNATURES = {
     "advhip_bn_fold_f32": (C.c_int, [_P, _P, _P, _P, C.c_float, _I, _P, _P, _P]),
     "advhip_conv3d_workspace_bytes": (_L, [C.POINTER(ConvDesc)]),
     "advhip_conv3d_bn_act_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "advhip_conv3d_bn_act_strided_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _L, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P]),
     "advhip_maxpool3d_f32": (C.c_int, [_P, _P] + [_I] * 11 + [_P]),
+    "advhip_maxpool3d_strided_f32": (C.c_int, [_P, _P, _L] + [_I] * 11 + [_P]),
     "advhip_global_avgpool_f32": (C.c_int, [_P, _P, _L, _I, _P]),
     "advhip_mil_magnitude_f32": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "advhip_mil_topk_select_f32": (C.c_int, [_P] * 7 + [_I] * 5 + [_P]),
@@ -131,7 +133,7 @@ def check(rc: int, what: str = "advhip") -> None:
         raise HipExtensionError(f"{what} failed (code {rc}): {msg}")
 
 
-def require_gpu(*tensors: torch.Tensor) -> None:
+def require_gpu(*tensors: torch.Tensor, contiguous: bool = True) -> None:
     for t in tensors:
         if t is None:
             continue
@@ -142,7 +144,7 @@ def require_gpu(*tensors: torch.Tensor) -> None:
             )
         if t.dtype not in (torch.float32, torch.int64, torch.int32, torch.uint8):
             raise HipExtensionError(f"unsupported dtype {t.dtype}; the kernels compute in fp32")
-        if not t.is_contiguous():
+        if contiguous and not t.is_contiguous():
             raise HipExtensionError("HIP kernels need contiguous tensors")
 
 

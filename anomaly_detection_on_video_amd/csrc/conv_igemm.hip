@@ -69,6 +69,8 @@ struct ConvArgs {
   const float* res;   // nullable, same shape as y
   float* y;           // output, or the split-K partial slabs [splits][B*Cout*THWo]
   int B, Cin, T, H, W, Cout;
+  int x_bstride;      // elements between consecutive samples of x (Cin*T*H*W when dense; larger for a channel slice of a wider tensor)
+  int y_bstride;      // same for y (the fused-epilogue output only: split-K slabs and the residual are dense)
   int st, sh, sw, pt, ph, pw;
   int To, Ho, Wo;
   int M, Kpad;
@@ -168,7 +170,8 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[B
         vec_load<4>(&st[row * Cfg::ST_STRIDE + rcol], v);
         if (mok) {
           const int n = n0 + wn * Cfg::WN + FN * row + jn;
-          const size_t o = (size_t)(bb * a.Cout + n) * a.THWo + pp;
+          const size_t o = (size_t)(bb * a.Cout + n) * a.THWo + pp;                                  // dense: residual, slabs
+          const size_t oy = fused ? (size_t)bb * a.y_bstride + (size_t)n * a.THWo + pp : o;  // output proper
           if (fused) {
             const float sc = a.scale[n], sf = a.shift[n];
 #pragma unroll
@@ -184,7 +187,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[B
               for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
           }
-          vec_store<4>(yout + o, v);
+          vec_store<4>(yout + oy, v);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -211,6 +214,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[B
         for (int jn = 0; jn < FN; ++jn) {
           const int n = n_lane + jn;
           const size_t o = (size_t)(bb * a.Cout + n) * a.THWo + pp;
+          const size_t oy = fused ? (size_t)bb * a.y_bstride + (size_t)n * a.THWo + pp : o;
           float vals[VW];
 #pragma unroll
           for (int e = 0; e < VW; ++e) vals[e] = acc[v0 + e][jn][r];
@@ -229,7 +233,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[B
               for (int e = 0; e < VW; ++e) vals[e] = fmaxf(vals[e], 0.f);
             }
           }
-          vec_store<VW>(yout + o, vals);
+          vec_store<VW>(yout + oy, vals);
         }
       }
     }
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_f32_kernel(const ConvArgs a)
   }
   const int it0 = ot * a.st - a.pt, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
   const unsigned Tlim = mv ? (unsigned)a.T : 0u;  // m out of range -> every tap invalid
-  const int mbase = b * a.Cin * a.THW + it0 * a.HW + ih0 * a.W + iw0;
+  const int mbase = b * a.x_bstride + it0 * a.HW + ih0 * a.W + iw0;
 
   float ra[RA];
   float rb[RB][4];
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_fast_kernel(const ConvArgs a
     const int oh = (int)a.dWo.div((unsigned)q);
     const int ow = q - oh * a.Wo;
     const int it0 = ot * a.st - a.pt, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
-    vbase = (unsigned)(b * a.Cin * a.THW + it0 * a.HW + ih0 * a.W + iw0 + a.pad_off) * 4u;
+    vbase = (unsigned)(b * a.x_bstride + it0 * a.HW + ih0 * a.W + iw0 + a.pad_off) * 4u;
     if constexpr (CHECK) {
       // a tap (dt,dh,dw) is inside the input iff each coordinate is: keep one bit per coordinate
       // value (bits 0-9: dt, 10-19: dh, 20-29: dw); the table holds the three bits a row needs
@@ -687,7 +691,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
     const int oh = (int)a.dWo.div((unsigned)q);
     const int ow = q - oh * a.Wo;
     const int it0 = ot * a.st - a.pt, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
-    vbase = (unsigned)(b * a.Cin * a.THW + it0 * a.HW + ih0 * a.W + iw0 + a.pad_off) * 4u;
+    vbase = (unsigned)(b * a.x_bstride + it0 * a.HW + ih0 * a.W + iw0 + a.pad_off) * 4u;
     if constexpr (CHECK) {
       vmask = tap_bits(it0, a.kt_, a.T) | (tap_bits(ih0, a.kh_, a.H) << 10) | (tap_bits(iw0, a.kw_, a.W) << 20);
     }
@@ -885,7 +889,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(const ConvArgs
     const int oh = (int)a.dWo.div((unsigned)q);
     const int ow = q - oh * a.Wo;
     const int it0 = ot * a.st - a.pt, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
-    vbase = (unsigned)(b * a.Cin * a.THW + it0 * a.HW + ih0 * a.W + iw0 + a.pad_off) * 4u;
+    vbase = (unsigned)(b * a.x_bstride + it0 * a.HW + ih0 * a.W + iw0 + a.pad_off) * 4u;
     if constexpr (CHECK) vmask = tap_bits(it0, a.kt_, a.T) | (tap_bits(ih0, a.kh_, a.H) << 10) | (tap_bits(iw0, a.kw_, a.W) << 20);
   }
   const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) - a.pad_off, 0, a.x_bytes, 0x00020000);
@@ -1234,6 +1238,14 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
                                         const int32_t* ktab, const float* scale, const float* shift,
                                         const float* residual, float* y, void* workspace, int64_t workspace_bytes,
                                         void* stream) {
+  return advhip_conv3d_bn_act_strided_f32(d, x, 0, w_packed, ktab, scale, shift, residual, y, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int advhip_conv3d_bn_act_strided_f32(const advhip_conv3d_desc* d, const float* x, int64_t x_batch_stride,
+                                                const float* w_packed, const int32_t* ktab, const float* scale,
+                                                const float* shift, const float* residual, float* y,
+                                                int64_t y_batch_stride, void* workspace, int64_t workspace_bytes,
+                                                void* stream) {
   if (int rc = validate(d)) return rc;
   ADVHIP_REQUIRE(x && w_packed && ktab && scale && shift && y, "conv3d: null pointer");
   const Geometry g = geometry(d);
@@ -1243,13 +1255,19 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
   a.B = d->B; a.Cin = d->Cin; a.T = d->T; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
   a.st = d->st; a.sh = d->sh; a.sw = d->sw; a.pt = d->pt; a.ph = d->ph; a.pw = d->pw;
   a.To = g.To; a.Ho = g.Ho; a.Wo = g.Wo;
-  const long long in_elems = (long long)d->B * d->Cin * d->T * d->H * d->W;
+  const long long x_dense = (long long)d->Cin * d->T * d->H * d->W, y_dense = (long long)d->Cout * g.To * g.Ho * g.Wo;
+  const long long xbs = x_batch_stride > 0 ? x_batch_stride : x_dense, ybs = y_batch_stride > 0 ? y_batch_stride : y_dense;
+  ADVHIP_REQUIRE(xbs >= x_dense && ybs >= y_dense, "conv3d: batch strides (%lld, %lld) smaller than one sample (%lld, %lld)", xbs, ybs, x_dense, y_dense);
+  // span of x in elements (the last sample is not padded out to the stride)
+  const long long in_elems = (long long)(d->B - 1) * xbs + x_dense;
   const long long M = g.M;
-  if (in_elems >= (1ll << 31) || M * d->Cout >= (1ll << 32) || M >= (1ll << 31)) {
+  if (in_elems >= (1ll << 31) || (long long)d->B * ybs >= (1ll << 32) || M * d->Cout >= (1ll << 32) || M >= (1ll << 31)) {
     set_error("conv3d: tensor too large for 32-bit indexing (in=%lld, out=%lld elements)", in_elems, M * d->Cout);
     return ADVHIP_ERANGE;
   }
   a.M = (int)M;
+  a.x_bstride = (int)xbs;
+  a.y_bstride = (int)ybs;
   a.Kpad = g.Kpad;
   a.HWo = a.Ho * a.Wo; a.THWo = a.To * a.HWo;
   a.HW = d->H * d->W; a.THW = d->T * a.HW;
@@ -1259,7 +1277,8 @@ extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float
   a.dWo = FastDiv::make((unsigned)a.Wo);
   a.vw = (a.THWo % 4 == 0) ? 4 : (a.THWo % 2 == 0 ? 2 : 1);
 
-  const Choice c = choose(d, M, g.Kpad);
+  Choice c = choose(d, M, g.Kpad);
+  if (ybs != y_dense) c.splits = 1;  // the split-K reduce pass writes a dense y
   int BM, BN, BK;
   tile_of(c.algo, &BM, &BN, &BK);
   const bool fast = c.algo >= ADVHIP_ALGO_FAST_BASE;  // includes the LDS-DMA and split-bf16 ids

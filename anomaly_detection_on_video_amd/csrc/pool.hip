@@ -10,8 +10,11 @@ namespace advhip {
 
 // One thread per output element, consecutive threads along W (coalesced stores; the window
 // reads of neighbouring threads overlap and are served by L1/L2).
+// `ypad` = extra elements between consecutive samples of y (0 when dense; y may be a channel slice of a wider tensor);
+// `per_sample` = C*To*Ho*Wo.
 __global__ void maxpool3d_kernel(const float* __restrict__ x, float* __restrict__ y, int T, int H, int W, int To,
-                                 int Ho, int Wo, int kt, int kh, int kw, int st, int sh, int sw, long long total) {
+                                 int Ho, int Wo, int kt, int kh, int kw, int st, int sh, int sw, long long total,
+                                 long long per_sample, long long ypad) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int wo = (int)(i % Wo);
@@ -29,7 +32,7 @@ __global__ void maxpool3d_kernel(const float* __restrict__ x, float* __restrict_
           // torch's max pooling propagates NaN
           m = (v > m || v != v) ? v : m;
         }
-    y[i] = m;
+    y[i + (i / per_sample) * ypad] = m;
   }
 }
 
@@ -38,7 +41,8 @@ __global__ void maxpool3d_kernel(const float* __restrict__ x, float* __restrict_
 // (columns 2l, 2l+1); the third column of a window comes from the next lane by shuffle, so every
 // input element is loaded by at most two waves (vs 2.25 scattered dword loads per element before).
 __global__ __launch_bounds__(256) void maxpool3d_233_kernel(const float* __restrict__ x, float* __restrict__ y, int T,
-                                                            int H, int W, int To, int Ho, int Wo, long long rows) {
+                                                            int H, int W, int To, int Ho, int Wo, long long rows,
+                                                            long long rows_per_sample, long long ypad) {
   const int lane = threadIdx.x & 63;
   const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);  // (bc, to, ho)
   if (row >= rows) return;
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(256) void maxpool3d_233_kernel(const float* __restr
       isnan_ |= (v.x != v.x) | (v.y != v.y) | (nx != nx);
       m = fmaxf(m, w3);
     }
-  if (lane < Wo) y[row * Wo + lane] = isnan_ ? NAN : m;  // torch's max pooling propagates NaN
+  if (lane < Wo) y[row * Wo + lane + (row / rows_per_sample) * ypad] = isnan_ ? NAN : m;  // torch's max pooling propagates NaN
 }
 
 // Temporal-only pooling (kh = kw = 1, sh = sw = 1): y[bc,to,p] = max_a x[bc, to*st + a, p]; four
@@ -115,27 +119,37 @@ using namespace advhip;
 extern "C" int advhip_maxpool3d_f32(const float* x, float* y, int32_t B, int32_t C, int32_t T, int32_t H, int32_t W,
                                     int32_t kt, int32_t kh, int32_t kw, int32_t st, int32_t sh, int32_t sw,
                                     void* stream) {
+  return advhip_maxpool3d_strided_f32(x, y, 0, B, C, T, H, W, kt, kh, kw, st, sh, sw, stream);
+}
+
+extern "C" int advhip_maxpool3d_strided_f32(const float* x, float* y, int64_t y_batch_stride, int32_t B, int32_t C, int32_t T,
+                                            int32_t H, int32_t W, int32_t kt, int32_t kh, int32_t kw, int32_t st, int32_t sh,
+                                            int32_t sw, void* stream) {
   ADVHIP_REQUIRE(x && y, "maxpool3d: null pointer");
   ADVHIP_REQUIRE(B > 0 && C > 0 && T >= kt && H >= kh && W >= kw && kt > 0 && kh > 0 && kw > 0 && st > 0 && sh > 0 && sw > 0,
                  "maxpool3d: bad shape (B=%d C=%d T=%d H=%d W=%d k=%d,%d,%d s=%d,%d,%d)", B, C, T, H, W, kt, kh, kw, st, sh, sw);
   const int To = (T - kt) / st + 1, Ho = (H - kh) / sh + 1, Wo = (W - kw) / sw + 1;
   const long long total = (long long)B * C * To * Ho * Wo;
+  const long long per_sample = (long long)C * To * Ho * Wo;
+  ADVHIP_REQUIRE(y_batch_stride == 0 || y_batch_stride >= per_sample, "maxpool3d: y batch stride %lld < one sample (%lld)",
+                 (long long)y_batch_stride, per_sample);
+  const long long ypad = y_batch_stride > 0 ? y_batch_stride - per_sample : 0;
   if (kt == 2 && kh == 3 && kw == 3 && st == 2 && sh == 2 && sw == 2 && W % 2 == 0 && W <= 128 && Wo < 64) {
     const long long rows = (long long)B * C * To * Ho;
     const long long blocks = (rows + 3) / 4;
     ADVHIP_REQUIRE(blocks < (1ll << 31), "maxpool3d: too many rows");
     hipLaunchKernelGGL(maxpool3d_233_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, T, H, W, To,
-                       Ho, Wo, rows);
+                       Ho, Wo, rows, (long long)C * To * Ho, ypad);
     return check_launch("maxpool3d_233");
   }
-  if (kh == 1 && kw == 1 && sh == 1 && sw == 1) {
+  if (kh == 1 && kw == 1 && sh == 1 && sw == 1 && ypad == 0) {
     const int grid = (int)std::min<long long>((total + 1023) / 1024, 256 * 16);
     hipLaunchKernelGGL(maxpool3d_t_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, T, H * W, To, kt, st, total);
     return check_launch("maxpool3d_t");
   }
   const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 32);
   hipLaunchKernelGGL(maxpool3d_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, T, H, W, To, Ho, Wo, kt, kh,
-                     kw, st, sh, sw, total);
+                     kw, st, sh, sw, total, per_sample, ypad);
   return check_launch("maxpool3d");
 }
 

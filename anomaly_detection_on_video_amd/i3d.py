@@ -87,6 +87,8 @@ class I3Res50(nn.Module):
                 m.bias.data.zero_()
         self._plan: Optional[List["_Unit"]] = None
         self._plan_stamp: Optional[Tuple] = None
+        # fold a stride-1 downsample branch (layer1.0) into conv3 as one conv over [x ; h] (see prepare)
+        self.fuse_downsample = os.environ.get("ADV_I3D_FUSE_DS", "1") == "1"
         # a forward is spread over this many HIP streams, each taking a contiguous part of the batch (see _run_streams)
         self.streams = int(os.environ.get("ADV_I3D_STREAMS", "2"))
         self._side_streams: List[torch.cuda.Stream] = []
@@ -115,6 +117,20 @@ class I3Res50(nn.Module):
         return ops.pack_conv(conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
                              conv.stride, conv.padding, name=name, algo=self.algo_overrides.get(name, _lib.ALGO_AUTO))
 
+    def _pack_fused(self, conv_x: nn.Conv3d, bn_x: nn.BatchNorm3d, conv_h: nn.Conv3d, bn_h: nn.BatchNorm3d, name: str) -> ops.PackedConv:
+        """bn_x(conv_x(x)) + bn_h(conv_h(h)) as one bias-free 1x1x1 conv over [x ; h]: each branch's BN scale goes into
+        its weight rows, the shifts add up; the packed conv then carries scale = 1 (gamma 1, var 1, eps 0)."""
+        def fold(bn):
+            scale = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
+            return scale, bn.bias.detach() - bn.running_mean.detach() * scale
+
+        sx, bx = fold(bn_x)
+        sh, bh = fold(bn_h)
+        w = torch.cat([conv_x.weight.detach() * sx.view(-1, 1, 1, 1, 1), conv_h.weight.detach() * sh.view(-1, 1, 1, 1, 1)], dim=1).contiguous()
+        one, zero = torch.ones_like(sx), torch.zeros_like(sx)
+        return ops.pack_conv(w, one, bx + bh, zero, one, 0.0, (1, 1, 1), (0, 0, 0), name=name,
+                             algo=self.algo_overrides.get(name, _lib.ALGO_AUTO))
+
     def prepare(self, force: bool = False) -> None:
         """Fold BN and pack weights into the kernels' layout (once; redone if parameters change)."""
         stamp = self._stamp()
@@ -133,6 +149,22 @@ class I3Res50(nn.Module):
             for bi, blk in enumerate(getattr(self, lname)):
                 p = f"{lname}.{bi}"
                 ds = None
+                if (self.fuse_downsample and blk.downsample is not None and tuple(blk.downsample[0].stride) == (1, 1, 1)
+                        and tuple(blk.conv2.stride) == (1, 1, 1) and plan[-1].kind == "maxpool"):
+                    # layer1.0: the downsample branch sees the same positions as conv3 (stride 1), so
+                    # conv3(h) + downsample(x) is ONE 1x1x1 conv over the channel concatenation [x ; h] with the two
+                    # BN scales folded into the weights.  The producers write straight into the two halves of one
+                    # buffer (the pool: channels [0, inplanes), conv2: the rest): no torch.cat, and the 64->256
+                    # downsample output (396 MB at B=32) is neither written nor read back as a residual.
+                    plan[-1].cat_channels = blk.conv3.in_channels
+                    plan.append(_Unit(
+                        "bottleneck",
+                        self._pack(blk.conv1, blk.bn1, f"{p}.conv1"),
+                        self._pack(blk.conv2, blk.bn2, f"{p}.conv2"),
+                        self._pack_fused(blk.downsample[0], blk.downsample[1], blk.conv3, blk.bn3, f"{p}.conv3+downsample"),
+                        None, name=p, cat=blk.downsample[0].in_channels,
+                    ))
+                    continue
                 if blk.downsample is not None:
                     ds = self._pack(blk.downsample[0], blk.downsample[1], f"{p}.downsample")
                 plan.append(_Unit(
@@ -196,7 +228,7 @@ class I3Res50(nn.Module):
                     if pool:
                         mark()
                     if taps is not None and u.name:
-                        taps[u.name] = x
+                        taps[u.name] = x[:, : x.shape[1] - u.cat_channels] if u.kind == "maxpool" and u.cat_channels else x
             if events is not None:
                 mark()
         return x
@@ -261,20 +293,31 @@ class I3Res50(nn.Module):
 class _Unit:
     """One step of the flat execution plan."""
 
-    def __init__(self, kind, *convs, name: str = "", kernel=None, stride=None):
+    def __init__(self, kind, *convs, name: str = "", kernel=None, stride=None, cat: int = 0):
         self.kind = kind
         self.convs = convs
         self.name = name or kind
         self.kernel, self.stride = kernel, stride
+        self.cat = cat            # bottleneck: > 0 = input is the [x ; h] buffer, x = its first `cat` channels
+        self.cat_channels = 0     # maxpool: > 0 = allocate that many extra channels behind the pooled ones
 
     def run(self, x: torch.Tensor) -> torch.Tensor:
         if self.kind == "stem":
             return ops.conv3d_bn_act(x, self.convs[0], relu=True)
         if self.kind == "maxpool":
+            if self.cat_channels:
+                to, ho, wo = ops.conv_out_dims(tuple(x.shape[2:]), self.kernel, self.stride, (0, 0, 0))
+                wide = torch.empty((x.shape[0], x.shape[1] + self.cat_channels, to, ho, wo), device=x.device, dtype=torch.float32)
+                ops.maxpool3d(x, self.kernel, self.stride, out=wide[:, : x.shape[1]])
+                return wide
             return ops.maxpool3d(x, self.kernel, self.stride)
         if self.kind == "avgpool":
             return ops.global_avgpool(x)
         c1, c2, c3, ds = self.convs
+        if self.cat:  # x is the wide buffer [x ; room for h]: conv2 writes h into its second half, c3 is the fused conv
+            h = ops.conv3d_bn_act(x[:, : self.cat], c1, relu=True)
+            ops.conv3d_bn_act(h, c2, relu=True, out=x[:, self.cat :])
+            return ops.conv3d_bn_act(x, c3, relu=True)
         h = ops.conv3d_bn_act(x, c1, relu=True)
         h = ops.conv3d_bn_act(h, c2, relu=True)
         res = ops.conv3d_bn_act(x, ds, relu=False) if ds is not None else x

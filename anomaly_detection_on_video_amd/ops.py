@@ -150,10 +150,24 @@ def workspace(dev: torch.device, nbytes: int) -> Optional[torch.Tensor]:
     return ws
 
 
+def batch_stride(t: torch.Tensor) -> int:
+    """Elements between consecutive samples of an NCDHW tensor that is contiguous per sample: a contiguous tensor,
+    or a channel slice `wide[:, a:b]` of one (the kernels take the batch stride; everything inside a sample must be
+    dense).  Raises for any other layout."""
+    n, c, t_, h, w = t.shape
+    inner = (t_ * h * w, h * w, w, 1)
+    for dim in range(1, 5):
+        if t.shape[dim] > 1 and t.stride(dim) != inner[dim - 1]:
+            raise ValueError(f"tensor {tuple(t.shape)} with strides {tuple(t.stride())} is not dense within a sample")
+    return int(t.stride(0)) if n > 1 else c * inner[0]
+
+
 def conv3d_bn_act(x: torch.Tensor, pc: PackedConv, relu: bool = True, residual: Optional[torch.Tensor] = None,
                   algo: Optional[int] = None, out: Optional[torch.Tensor] = None, splits: Optional[int] = None) -> torch.Tensor:
-    """act(conv3d(x) * scale + shift (+ residual)) in one fused HIP launch."""
-    require_gpu(x, residual)
+    """act(conv3d(x) * scale + shift (+ residual)) in one fused HIP launch.  `x` and `out` may be channel slices of wider
+    NCDHW tensors (see batch_stride); the residual must be contiguous."""
+    require_gpu(x, out, contiguous=False)
+    require_gpu(residual)
     if x.dim() != 5 or x.shape[1] != pc.cin:
         raise ValueError(f"{pc.name}: expected (B,{pc.cin},T,H,W), got {tuple(x.shape)}")
     B, _, T, H, W = x.shape
@@ -175,18 +189,29 @@ def conv3d_bn_act(x: torch.Tensor, pc: PackedConv, relu: bool = True, residual: 
     w = pc.w_packed
     if _lib.ALGO_BF16X3_BASE <= d.algo < _lib.ALGO_DMA2_BASE:
         w = split_weight(pc)
-    check(lib.advhip_conv3d_bn_act_f32(C.byref(d), ptr(x), ptr(w), ptr(ktab), ptr(pc.scale), ptr(pc.shift),
-                                       ptr(residual), ptr(y), ptr(ws), need, stream()), f"conv3d[{pc.name}]")
+    xbs, ybs = batch_stride(x), batch_stride(y)
+    if xbs == pc.cin * T * H * W and ybs == pc.cout * to * ho * wo:
+        check(lib.advhip_conv3d_bn_act_f32(C.byref(d), ptr(x), ptr(w), ptr(ktab), ptr(pc.scale), ptr(pc.shift),
+                                           ptr(residual), ptr(y), ptr(ws), need, stream()), f"conv3d[{pc.name}]")
+    else:  # x and / or y is a channel slice of a wider tensor
+        check(lib.advhip_conv3d_bn_act_strided_f32(C.byref(d), ptr(x), xbs, ptr(w), ptr(ktab), ptr(pc.scale), ptr(pc.shift),
+                                                   ptr(residual), ptr(y), ybs, ptr(ws), need, stream()), f"conv3d[{pc.name}]")
     return y
 
 
-def maxpool3d(x: torch.Tensor, kernel, stride) -> torch.Tensor:
+def maxpool3d(x: torch.Tensor, kernel, stride, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`out`: optional destination, contiguous or a channel slice of a wider NCDHW tensor."""
     require_gpu(x)
+    require_gpu(out, contiguous=False)
     B, Cc, T, H, W = x.shape
     k, s = _triple(kernel), _triple(stride)
     to, ho, wo = conv_out_dims((T, H, W), k, s, (0, 0, 0))
-    y = torch.empty((B, Cc, to, ho, wo), device=x.device, dtype=torch.float32)
-    check(_lib.load().advhip_maxpool3d_f32(ptr(x), ptr(y), B, Cc, T, H, W, *k, *s, stream()), "maxpool3d")
+    y = out if out is not None else torch.empty((B, Cc, to, ho, wo), device=x.device, dtype=torch.float32)
+    if tuple(y.shape) != (B, Cc, to, ho, wo):
+        raise ValueError(f"maxpool3d: out {tuple(y.shape)} != {(B, Cc, to, ho, wo)}")
+    ybs = batch_stride(y)
+    check(_lib.load().advhip_maxpool3d_strided_f32(ptr(x), ptr(y), 0 if ybs == Cc * to * ho * wo else ybs, B, Cc, T, H, W, *k, *s, stream()),
+          "maxpool3d")
     return y
 
 

@@ -116,10 +116,23 @@ int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float* x, const 
                              const float* residual, float* y, void* workspace,
                              int64_t workspace_bytes, void* stream);
 
+/* The same with explicit batch strides (in elements; 0 = dense): x and/or y may be a channel slice of a wider NCDHW
+ * tensor, e.g. one half of a concatenation buffer -- how the layer-1 downsample branch is folded into conv3 (one conv
+ * over [x ; h] written by their producers into one buffer, no torch.cat, no residual round trip).  The residual and the
+ * split-K slabs stay dense; a strided y runs unsplit. */
+int advhip_conv3d_bn_act_strided_f32(const advhip_conv3d_desc* d, const float* x, int64_t x_batch_stride,
+                                     const float* w_packed, const int32_t* ktab, const float* scale, const float* shift,
+                                     const float* residual, float* y, int64_t y_batch_stride, void* workspace,
+                                     int64_t workspace_bytes, void* stream);
+
 /* nn.MaxPool3d with zero padding=0, floor mode (src/i3d.py:212-217, 306, 309). */
 int advhip_maxpool3d_f32(const float* x, float* y, int32_t B, int32_t C, int32_t T, int32_t H,
                          int32_t W, int32_t kt, int32_t kh, int32_t kw, int32_t st, int32_t sh,
                          int32_t sw, void* stream);
+
+/* The same, y being a channel slice of a wider tensor (y_batch_stride in elements, 0 = dense). */
+int advhip_maxpool3d_strided_f32(const float* x, float* y, int64_t y_batch_stride, int32_t B, int32_t C, int32_t T, int32_t H,
+                                 int32_t W, int32_t kt, int32_t kh, int32_t kw, int32_t st, int32_t sh, int32_t sw, void* stream);
 
 /* nn.AdaptiveAvgPool3d((1,1,1)) (src/i3d.py:244, 314): x (rows, n) -> y (rows), mean over n. */
 int advhip_global_avgpool_f32(const float* x, float* y, int64_t rows, int32_t n, void* stream);

@@ -111,6 +111,39 @@ def test_conv_bn_act_vs_oracle(case, algo):
         assert e < TOL
 
 
+def test_conv_and_pool_on_channel_slices():
+    """x / y as channel slices of wider NCDHW buffers (batch stride > one sample): how layer1.0's downsample branch is
+    folded into conv3 -- the pool writes channels [0,64) and conv2 channels [64,128) of one buffer, and a 128-channel
+    1x1x1 conv reads it.  Same numbers as on dense tensors, neighbours of the slices untouched."""
+    from anomaly_detection_on_video_amd import ops
+    from oracle import i3d_oracle
+
+    dev = _dev()
+    name, cin, cout, k, s, p, bthw = next(c for c in CONV_CASES if c[0] == "l1.conv2")
+    x, wt, g, be, mu, var, res = _conv_case(name, cin, cout, k, s, p, bthw)
+    pc = ops.pack_conv(wt.to(dev), g.to(dev), be.to(dev), mu.to(dev), var.to(dev), 1e-5, s, p, name=name)
+    b, t, h, w = bthw
+    wide_in = torch.full((b, cin + 24, t, h, w), 7.0, device=dev)
+    wide_in[:, 8 : 8 + cin] = x.to(dev)
+    wide_out = torch.full((b, cout + 40, t, h, w), -3.0, device=dev)
+    dense = ops.conv3d_bn_act(x.to(dev), pc, relu=True, residual=res.to(dev))
+    for algo in (None, 67, 163, 35, 3, 134):
+        wide_out.fill_(-3.0)
+        got = ops.conv3d_bn_act(wide_in[:, 8 : 8 + cin], pc, relu=True, residual=res.to(dev), out=wide_out[:, 16 : 16 + cout], algo=algo)
+        if algo in (None, 67):
+            assert torch.equal(got, dense) or rel_err(got.cpu(), dense.cpu()) < TIGHT
+        assert rel_err(got.cpu(), i3d_oracle.conv_bn_act(x, wt, g, be, mu, var, s, p, res, True)) < (BF16X3_TOL if algo == 134 else TIGHT)
+        assert (wide_out[:, :16] == -3.0).all() and (wide_out[:, 16 + cout :] == -3.0).all()
+    with pytest.raises(ValueError):
+        ops.conv3d_bn_act(wide_in[:, :, :, :, ::2][:, :cin], pc)
+    xp = synth_tensor("slice.pool", (2, 6, 4, 12, 10), scale=2.0).to(dev)
+    for kk, ss in (((2, 3, 3), (2, 2, 2)), ((2, 1, 1), (2, 1, 1)), ((1, 2, 2), (1, 1, 1))):
+        ref = ops.maxpool3d(xp, kk, ss)
+        wide = torch.full((2, 11) + tuple(ref.shape[2:]), 5.0, device=dev)
+        ops.maxpool3d(xp, kk, ss, out=wide[:, 3:9])
+        assert torch.equal(wide[:, 3:9], ref) and (wide[:, :3] == 5.0).all() and (wide[:, 9:] == 5.0).all()
+
+
 BF16X3_TOL = 1e-4  # split-bf16 arithmetic (hi*hi + hi*lo + lo*hi): ~2^-16 per product; the contract is TOL = 1e-3
 
 

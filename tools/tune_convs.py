@@ -107,6 +107,9 @@ def main():
             c1, c2, c3, ds = u.convs
             o1 = tune(c1, cur, True, None)
             o2 = tune(c2, o1, True, None)
+            if u.cat:  # conv3 + downsample folded into one conv over [x ; h]
+                cur = tune(c3, torch.cat([cur, o2], dim=1), True, None)
+                continue
             r = tune(ds, cur, False, None) if ds is not None else cur
             cur = tune(c3, o2, True, r)
     print(f"sum of best conv times {total_best:.2f} ms -> {args.batch / total_best * 1e3:.0f} clips/s, {tot_flop / total_best / 1e9:.1f} TFLOP/s")
