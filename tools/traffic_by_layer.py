@@ -23,9 +23,12 @@ def layers(B=32):
             out.append((f"{name}.{b}.conv1", inpl, planes, (kt, 1, 1), (1, 1, 1), (T, H, H), False))
             out.append((f"{name}.{b}.conv2", planes, planes, (1, 3, 3), (1, s, s), (T, H, H), False))
             Ho = (H + 2 - 3) // s + 1
-            if b == 0:
-                out.append((f"{name}.{b}.downsample", inpl, planes * 4, (1, 1, 1), (1, s, s), (T, H, H), False))
-            out.append((f"{name}.{b}.conv3", planes, planes * 4, (1, 1, 1), (1, 1, 1), (T, Ho, Ho), True))
+            if b == 0 and s == 1:  # layer1.0: downsample folded into conv3 (one conv over [x ; h], no residual)
+                out.append((f"{name}.{b}.conv3+downsample", inpl + planes, planes * 4, (1, 1, 1), (1, 1, 1), (T, Ho, Ho), False))
+            else:
+                if b == 0:
+                    out.append((f"{name}.{b}.downsample", inpl, planes * 4, (1, 1, 1), (1, s, s), (T, H, H), False))
+                out.append((f"{name}.{b}.conv3", planes, planes * 4, (1, 1, 1), (1, 1, 1), (T, Ho, Ho), True))
             H = Ho
             inpl = planes * 4
     res = []
