@@ -105,7 +105,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or os.environ.get("ADVHIP_LIBRARY") or LIB_PATH  # ADVHIP_LIBRARY: another build of the same ABI (diagnostic builds)
+    p = path or LIB_PATH
     if not os.path.exists(p):
         raise HipExtensionError(
             f"{p} not found: the HIP extension has not been built. Run "
@@ -134,9 +134,21 @@ def check(rc: int, what: str = "advhip") -> None:
 
 
 def require_gpu(*tensors: torch.Tensor, contiguous: bool = True) -> None:
+    dev = None
     for t in tensors:
         if t is None:
             continue
+        if t.is_cuda:
+            if dev is None:
+                dev = t.device
+                if dev.index is not None and dev.index != torch.cuda.current_device():
+                    # kernels launch on the CURRENT device: a tensor elsewhere would be read through peer access (or
+                    # fault) on a stream that orders nothing on its own device
+                    raise HipExtensionError(
+                        f"tensor on {dev} but the current device is cuda:{torch.cuda.current_device()}: "
+                        "call torch.cuda.set_device (one process per GPU)")
+            elif t.device != dev:
+                raise HipExtensionError(f"tensors on different devices: {dev} and {t.device}")
         if not t.is_cuda:
             raise HipExtensionError(
                 "this op runs only as a HIP kernel on an AMD GPU; got a tensor on "
@@ -152,5 +164,8 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def stream(dev=None) -> int:
+    """Raw hipStream_t of torch's current stream on `dev` (a tensor, a device, or None = the current device)."""
+    if isinstance(dev, torch.Tensor):
+        dev = dev.device
+    return torch.cuda.current_stream(dev).cuda_stream

@@ -19,7 +19,6 @@
 // Replaces nn.Conv3d + nn.BatchNorm3d(eval) + residual add + nn.ReLU of
 // /root/reference/src/i3d.py:98-121, 262-272, 303-305.
 #include <algorithm>
-#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -636,21 +635,6 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   static_assert(LB >= 1 && LA >= 1 && (NS - 2) * (LA + LB) <= 63, "tile / vmcnt budget");
   constexpr unsigned OOB = 0xFFFFFF00u;
   constexpr int RING = NS * D::STAGE;
-  // Diagnostic builds only (-DADVHIP_DIAG=bits, tools/diag_build.sh; results are wrong, timing is the point):
-  // 4 = the A rows of a wave as ONE 16-byte LDS-DMA instead of LA 4-byte ones, 8 = no A loads, 16 = no B loads,
-  // 32 = A in a channels-last access pattern.
-#ifdef ADVHIP_DIAG
-  constexpr int DIAG = ADVHIP_DIAG;
-#else
-  constexpr int DIAG = 0;
-#endif
-  constexpr int LAI = (DIAG & 8) ? 0 : (DIAG & 4) ? 1 : LA;  // A / B LDS-DMA instructions actually issued per wave per k-tile
-  constexpr int LBI = (DIAG & 16) ? 0 : LB;
-#if defined(ADVHIP_DIAG) && defined(__HIP_DEVICE_COMPILE__)  // (hipcc's host pass drops the kernel stub when it sees 16 here)
-  constexpr int ASZ = (DIAG & 4) ? 16 : 4;  // bytes per lane of an A LDS-DMA
-#else
-  constexpr int ASZ = 4;
-#endif
   constexpr int SMEM = RING > Cfg::ST_FLOATS ? RING : Cfg::ST_FLOATS;
 
   __shared__ __attribute__((aligned(16))) float smem[SMEM];
@@ -660,10 +644,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntiles = a.tiles_m * a.tiles_n;
   const int nitems = ntiles * a.splits;
-  // Persistent form: the grid may be smaller than the number of (tile, K-slice) work items; each
-  // workgroup then walks items blockIdx.x, blockIdx.x + gridDim.x, ... (a grid of nitems runs the
-  // body once).  Saves the workgroup re-dispatch between 50-microsecond tiles.
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+  const int item = (int)blockIdx.x;  // one (tile, K-slice) work item per workgroup (persistent grids measured slower)
   int L, split;
   // each XCD works on a contiguous range of (tile, K-slice) items: the K-slices of a tile and the n-tiles of an
   // m-tile (which re-read the same activation rows) meet in one L2
@@ -712,20 +693,15 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
     float* As = smem + stage * D::STAGE;
     float* Bs = As + BK * BM;
 #pragma unroll
-    for (int j = 0; j < LAI; ++j) {
-      if (j * nparts / (LAI ? LAI : 1) != part) continue;
+    for (int j = 0; j < LA; ++j) {
+      if (j * nparts / LA != part) continue;
       const int krow = kr * LA + j;
       unsigned voff = vbase;
       if constexpr (CHECK) voff = ((vmask & (unsigned)ent[2 * j + 1]) == (unsigned)ent[2 * j + 1]) ? vbase : OOB;
-      if constexpr (DIAG & 32) {  // the access pattern of a channels-last gather: 8 rows x 128 B per wave-instruction
-        voff = (unsigned)(((m0 >> 1) + wave * 8 + (lane >> 3)) * a.Cin * 4 + (((k0 >> 5) * 32) % a.Cin) * 4 + (lane & 7) * 16);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(As + krow * BM + a_wave_col), ASZ, voff, 0, 0, 0);
-      } else {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(As + krow * BM + a_wave_col), ASZ, voff, ent[2 * j], 0, 0);
-      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(As + krow * BM + a_wave_col), 4, voff, ent[2 * j], 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < LBI; ++j) {
+    for (int j = 0; j < LB; ++j) {
       if (j * nparts / LB != part) continue;
       const int row0 = (wave * LB + j) * RPW;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(Bs + row0 * BN), 16, wvoff, ((k0 + row0) * a.Cout + n0) * 4, 0, 0);
@@ -801,8 +777,8 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
     // tile kt has landed once only the loads of the younger tiles in flight (<= NS-2) are outstanding
     const int younger = kt1 - 1 - kt;
     if (NS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the only tile in flight is tile kt
-    else if (NS == 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LAI + LBI)) : "memory");
-    else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LAI + LBI) : "memory");
+    else if (NS == 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LA + LB)) : "memory");
+    else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA + LB) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");  // all waves' parts of tile kt are in LDS; stage (kt-1)%NS is free
     const bool pre = kt + NS - 1 < kt1;
@@ -812,8 +788,6 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   }
   __syncthreads();  // every wave is done with the ring before the epilogue reuses it as staging
   igemm_epilogue<BM, BN, BK>(a, acc, smem, split, m0, n0, wave, lane);
-  __syncthreads();  // ... and with the staging before the next item's DMA lands in it
-  }  // item loop
 }
 
 // ================================================================================================
@@ -1179,6 +1153,19 @@ static void tile_of(int algo, int* BM, int* BN, int* BK) {
   *BK = algo >= ADVHIP_ALGO_IGEMM_128x128x32 ? 32 : 16;
 }
 
+// Which (family, tile) ids have a kernel in this library.  Ids inside a family's range without an instantiation
+// (e.g. DMA_BASE + 5) are rejected up front: a launch switch that fell through would return OK with y unwritten.
+static bool instantiated(int algo) {
+  auto tile_in = [](int t, unsigned mask) { return t >= 1 && t <= 8 && ((mask >> t) & 1u); };
+  constexpr unsigned ALL = 0x1FEu, NO5 = ALL & ~(1u << 5);
+  if (algo >= ADVHIP_ALGO_DMA2_BASE) return tile_in(algo - ADVHIP_ALGO_DMA2_BASE, NO5);
+  if (algo >= ADVHIP_ALGO_BF16X3_BASE) return tile_in(algo - ADVHIP_ALGO_BF16X3_BASE, (1u << 5) | (1u << 6));
+  if (algo >= ADVHIP_ALGO_DMA4_BASE) return tile_in(algo - ADVHIP_ALGO_DMA4_BASE, (1u << 2) | (1u << 3) | (1u << 4));
+  if (algo >= ADVHIP_ALGO_DMA_BASE) return tile_in(algo - ADVHIP_ALGO_DMA_BASE, NO5);
+  if (algo >= ADVHIP_ALGO_FAST_BASE) return tile_in(algo - ADVHIP_ALGO_FAST_BASE, ALL);
+  return tile_in(algo, ALL);
+}
+
 // the fast kernel covers kernels up to 10x10x10 on tensors addressable by 32-bit byte offsets
 static bool fast_ok(const advhip_conv3d_desc* d, long long in_elems, long long w_elems) {
   const long long pad_off = (long long)d->pt * d->H * d->W + (long long)d->ph * d->W + d->pw;
@@ -1231,6 +1218,10 @@ extern "C" int64_t advhip_conv3d_workspace_bytes(const advhip_conv3d_desc* d) {
   if (validate(d)) return -1;
   const Geometry g = geometry(d);
   const Choice c = choose(d, g.M, g.Kpad);
+  if (!instantiated(c.algo)) {
+    set_error("conv3d: algo %d is not instantiated in this library", c.algo);
+    return -1;
+  }
   return c.splits > 1 ? (int64_t)c.splits * g.M * d->Cout * (int64_t)sizeof(float) : 0;
 }
 
@@ -1275,19 +1266,20 @@ extern "C" int advhip_conv3d_bn_act_strided_f32(const advhip_conv3d_desc* d, con
   a.dTHWo = FastDiv::make((unsigned)a.THWo);
   a.dHWo = FastDiv::make((unsigned)a.HWo);
   a.dWo = FastDiv::make((unsigned)a.Wo);
-  a.vw = (a.THWo % 4 == 0) ? 4 : (a.THWo % 2 == 0 ? 2 : 1);
+  // widest epilogue vector (floats) the output rows, the batch stride and the pointers are all aligned to
+  auto aligned_to = [&](int v) {
+    const uintptr_t bytes = (uintptr_t)v * sizeof(float);
+    return a.THWo % v == 0 && ybs % v == 0 && (uintptr_t)y % bytes == 0 && (uintptr_t)residual % bytes == 0 &&
+           (uintptr_t)workspace % bytes == 0;
+  };
+  a.vw = aligned_to(4) ? 4 : (aligned_to(2) ? 2 : 1);
 
   Choice c = choose(d, M, g.Kpad);
   if (ybs != y_dense) c.splits = 1;  // the split-K reduce pass writes a dense y
   int BM, BN, BK;
   tile_of(c.algo, &BM, &BN, &BK);
+  ADVHIP_REQUIRE(instantiated(c.algo), "conv3d: algo %d is not instantiated in this library", c.algo);
   const bool fast = c.algo >= ADVHIP_ALGO_FAST_BASE;  // includes the LDS-DMA and split-bf16 ids
-  const int base_algo = c.algo >= ADVHIP_ALGO_DMA2_BASE ? c.algo - ADVHIP_ALGO_DMA2_BASE
-                        : c.algo >= ADVHIP_ALGO_BF16X3_BASE ? c.algo - ADVHIP_ALGO_BF16X3_BASE
-                        : c.algo >= ADVHIP_ALGO_DMA4_BASE ? c.algo - ADVHIP_ALGO_DMA4_BASE
-                        : c.algo >= ADVHIP_ALGO_DMA_BASE ? c.algo - ADVHIP_ALGO_DMA_BASE
-                        : (fast ? c.algo - ADVHIP_ALGO_FAST_BASE : c.algo);
-  ADVHIP_REQUIRE(base_algo >= ADVHIP_ALGO_IGEMM_128x128 && base_algo <= ADVHIP_ALGO_IGEMM_64x128x32, "conv3d: unknown algo %d", c.algo);
   if (fast) {
     ADVHIP_REQUIRE(fast_ok(d, in_elems, (long long)g.Kpad * d->Cout),
                    "conv3d: fast kernel needs kernel extents <= 10 and < 3.75 GiB operands (k=%d,%d,%d)", d->kt, d->kh, d->kw);
@@ -1295,12 +1287,6 @@ extern "C" int advhip_conv3d_bn_act_strided_f32(const advhip_conv3d_desc* d, con
     a.pad_off = d->pt * d->H * d->W + d->ph * d->W + d->pw;
     a.x_bytes = (unsigned)((in_elems + a.pad_off) * 4);
     a.w_bytes = (unsigned)((long long)g.Kpad * d->Cout * 4);
-    // timing-only diagnostic (cdna_hip_programming.md section 7): zero-record descriptors make the
-    // buffer unit drop every operand load while the instruction stream, waits and barriers stay, which
-    // prices the memory side of the kernel.  Outputs are wrong by construction.
-    static const int zero_records = getenv("ADVHIP_DEBUG_ZERO_RECORDS") ? atoi(getenv("ADVHIP_DEBUG_ZERO_RECORDS")) : 0;
-    if (zero_records & 1) a.x_bytes = 0;  // timing diagnostic: every activation load is out of range -> returns 0, no memory access
-    if (zero_records & 2) a.w_bytes = 0;  // ... every weight load
   }
   ADVHIP_REQUIRE(d->Cout % BN == 0, "conv3d: Cout=%d not a multiple of the %d-wide N tile", d->Cout, BN);
   ADVHIP_REQUIRE(g.Kpad % BK == 0 || BK == 16, "conv3d: internal: Kpad");
@@ -1320,12 +1306,6 @@ extern "C" int advhip_conv3d_bn_act_strided_f32(const advhip_conv3d_desc* d, con
   a.dTilesN = FastDiv::make((unsigned)a.tiles_n);
   a.dSplits = FastDiv::make((unsigned)c.splits);
   dim3 grid((unsigned)(a.tiles_m * a.tiles_n * c.splits));
-  if ((c.algo >= ADVHIP_ALGO_DMA_BASE && c.algo < ADVHIP_ALGO_BF16X3_BASE) || c.algo >= ADVHIP_ALGO_DMA2_BASE) {
-    // persistent launch of the LDS-DMA kernel: at most `slots` workgroups per CU stay resident and
-    // loop over the work items (ADVHIP_PERSISTENT_SLOTS, 0 = one workgroup per item)
-    static const int slots = getenv("ADVHIP_PERSISTENT_SLOTS") ? atoi(getenv("ADVHIP_PERSISTENT_SLOTS")) : 0;
-    if (slots > 0 && grid.x > (unsigned)(256 * slots)) grid.x = 256u * slots;
-  }
   hipStream_t st = (hipStream_t)stream;
   // BK = 32 needs Kpad % 32 == 0: the packed weights are padded to 16 rows only, but the k-table
   // marks rows >= K invalid and the weight rows read beyond Kpad must exist -> require it.
@@ -1393,12 +1373,14 @@ extern "C" int advhip_conv3d_bn_act_strided_f32(const advhip_conv3d_desc* d, con
     case ADVHIP_ALGO_IGEMM_128x64x32: hipLaunchKernelGGL((conv3d_igemm_f32_kernel<128, 64, 32>), grid, dim3(256), 0, st, a); break;
     case ADVHIP_ALGO_IGEMM_64x64x32: hipLaunchKernelGGL((conv3d_igemm_f32_kernel<64, 64, 32>), grid, dim3(256), 0, st, a); break;
     case ADVHIP_ALGO_IGEMM_64x128x32: hipLaunchKernelGGL((conv3d_igemm_f32_kernel<64, 128, 32>), grid, dim3(256), 0, st, a); break;
-    default: break;
+    default:
+      set_error("conv3d: algo %d is not instantiated in this library", c.algo);
+      return ADVHIP_EINVAL;
   }
   if (int rc = check_launch("conv3d_igemm")) return rc;
   if (c.splits > 1) {
     const long long total = a.slab;
-    const int vec4 = (total % 4 == 0 && a.THWo % 4 == 0) ? 1 : 0;
+    const int vec4 = a.vw == 4 ? 1 : 0;  // rows, slabs, residual and y all 16-byte aligned
     const long long work = vec4 ? total / 4 : total;
     const int rgrid = (int)std::min<long long>((work + 255) / 256, 256 * 16);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rgrid), dim3(256), 0, st, reinterpret_cast<const float*>(workspace), scale,

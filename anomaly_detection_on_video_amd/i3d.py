@@ -233,10 +233,12 @@ class I3Res50(nn.Module):
                 mark()
         return x
 
-    def ensure_tables(self, thw: Tuple[int, int, int]) -> None:
-        """Pack the weights and build every conv's gather table for clips of dims (T,H,W) on the CURRENT stream.
-        Both happen lazily on whatever stream first needs them; a caller that is about to run forwards on other
-        streams (stream parts, pipeline lanes) calls this first and orders those streams after it."""
+    def ensure_tables(self, thw: Tuple[int, int, int], batch: Optional[int] = None) -> None:
+        """Pack the weights and build every conv's gather table for clips of dims (T,H,W) on the CURRENT stream;
+        with `batch`, also the split-bf16 weight images of every conv whose resolved choice for (batch,T,H,W) is a
+        split-bf16 kernel (ADV_ARITH=mixed / bf16x3).  All of these are created lazily on whatever stream first
+        needs them; a caller that is about to run forwards on other streams (stream parts, pipeline lanes) calls
+        this first and orders those streams after it."""
         self.prepare()
         dims = tuple(thw)
         for u in self._plan:
@@ -244,9 +246,9 @@ class I3Res50(nn.Module):
                 dims = ops.conv_out_dims(dims, u.kernel, u.stride, (0, 0, 0))
             elif u.kind in ("stem", "bottleneck"):
                 if u.kind == "bottleneck" and u.convs[3] is not None:
-                    ops.ensure_ktab(u.convs[3], dims)  # the downsample branch reads the unit's input
+                    ops.ensure_ktab(u.convs[3], dims, batch)  # the downsample branch reads the unit's input
                 for c in u.convs[:3]:
-                    ops.ensure_ktab(c, dims)
+                    ops.ensure_ktab(c, dims, batch)
                     dims = ops.conv_out_dims(dims, c.kernel, c.stride, c.padding)
 
     def _n_streams(self, batch: int) -> int:
@@ -262,7 +264,8 @@ class I3Res50(nn.Module):
         with the final ones."""
         B = x.shape[0]
         bounds = [(B * i) // n for i in range(n + 1)]
-        self.ensure_tables(tuple(x.shape[2:]))
+        for part_b in sorted({bounds[i + 1] - bounds[i] for i in range(n)}):
+            self.ensure_tables(tuple(x.shape[2:]), part_b)
         main = torch.cuda.current_stream(x.device)
         while len(self._side_streams) < n - 1:
             self._side_streams.append(torch.cuda.Stream(device=x.device))

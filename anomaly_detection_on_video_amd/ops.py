@@ -108,11 +108,17 @@ def split_weight(pc: PackedConv) -> torch.Tensor:
     return pc.w_split
 
 
-def ensure_ktab(pc: PackedConv, thw: Tuple[int, int, int]) -> torch.Tensor:
-    """The gather table of `pc` for input dims (T,H,W), built on the current stream on first use."""
+def ensure_ktab(pc: PackedConv, thw: Tuple[int, int, int], batch: Optional[int] = None) -> torch.Tensor:
+    """The gather table of `pc` for input dims (T,H,W), built on the current stream on first use.  With `batch`, also
+    every other lazily built operand the launch for (batch, T, H, W) will read -- today the bf16 hi/lo weight images
+    of the opt-in split-bf16 kernels -- so that a caller about to fork streams has ALL of them behind one event."""
     ktab = pc.ktabs.get(thw)
     if ktab is None:
         ktab = pc.ktabs[thw] = _build_ktab(pc, thw)
+    if batch is not None:
+        d = pc.desc(batch, *thw, relu=False)
+        if _lib.ALGO_BF16X3_BASE <= d.algo < _lib.ALGO_DMA2_BASE:
+            split_weight(pc)
     return ktab
 
 
@@ -175,6 +181,8 @@ def conv3d_bn_act(x: torch.Tensor, pc: PackedConv, relu: bool = True, residual: 
     if min(to, ho, wo) <= 0:
         raise ValueError(f"{pc.name}: input {tuple(x.shape)} smaller than the kernel")
     y = out if out is not None else torch.empty((B, pc.cout, to, ho, wo), device=x.device, dtype=torch.float32)
+    if tuple(y.shape) != (B, pc.cout, to, ho, wo) or y.dtype != torch.float32 or y.device != x.device:
+        raise ValueError(f"{pc.name}: out {tuple(y.shape)} {y.dtype} on {y.device} != {(B, pc.cout, to, ho, wo)} float32 on {x.device}")
     if residual is not None and residual.shape != y.shape:
         raise ValueError(f"{pc.name}: residual {tuple(residual.shape)} != output {tuple(y.shape)}")
     ktab = ensure_ktab(pc, (T, H, W))

@@ -45,7 +45,7 @@ class ExtractScoreStream:
         self._lane_streams: List[torch.cuda.Stream] = []
         self._lane_next = 0
         self._ordered: Optional[torch.cuda.Event] = None  # end of the previous step's gather + ingest
-        self._table_dims: set = set()                      # clip dims whose gather tables exist
+        self._table_dims: set = set()                      # (batch, T, H, W) whose lazily built operands exist
         self._tables_built: Optional[torch.cuda.Event] = None
 
     @torch.no_grad()
@@ -80,9 +80,12 @@ class ExtractScoreStream:
         # packed weights and gather tables are created lazily on the stream that first needs them: create them
         # before the lanes fork (dims known), or on this lane with an event every later lane step waits for
         tables = getattr(self.backbone, "ensure_tables", None)
-        if prepare is None and tables is not None and tuple(local_clips.shape[2:]) not in self._table_dims:
-            tables(tuple(local_clips.shape[2:]))
-            self._table_dims.add(tuple(local_clips.shape[2:]))
+        def table_key(t):
+            return (t.shape[0],) + tuple(t.shape[2:])  # the resolved kernel choices depend on the batch size too
+
+        if prepare is None and tables is not None and table_key(local_clips) not in self._table_dims:
+            tables(tuple(local_clips.shape[2:]), local_clips.shape[0])
+            self._table_dims.add(table_key(local_clips))
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))
         with torch.cuda.stream(lane):
@@ -91,9 +94,9 @@ class ExtractScoreStream:
                 lane.wait_event(self._tables_built)
             if prepare is not None:
                 local_clips = prepare(local_clips)
-                if tables is not None and tuple(local_clips.shape[2:]) not in self._table_dims:
-                    tables(tuple(local_clips.shape[2:]))
-                    self._table_dims.add(tuple(local_clips.shape[2:]))
+                if tables is not None and table_key(local_clips) not in self._table_dims:
+                    tables(tuple(local_clips.shape[2:]), local_clips.shape[0])
+                    self._table_dims.add(table_key(local_clips))
                     self._tables_built = torch.cuda.Event()
                     self._tables_built.record(lane)
             else:

@@ -39,3 +39,20 @@ def rel_err(a, b):
     a = torch.as_tensor(a, dtype=torch.float64)
     b = torch.as_tensor(b, dtype=torch.float64)
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def assert_close_elementwise(a, b, rtol=1e-3, afloor=1e-3):
+    """Element-wise parity: |a - b| <= rtol * |b| + afloor * rms(b) for EVERY element (the norm-wise `rel_err` lets
+    small elements be arbitrarily wrong; this one does not, with an absolute floor scaled to the tensor's own rms so
+    that exact zeros / ReLU-clamped entries do not demand infinite relative precision)."""
+    import torch
+
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    rms = float(b.pow(2).mean().sqrt())
+    excess = (a - b).abs() - (rtol * b.abs() + afloor * rms)
+    worst = int(excess.argmax())
+    assert float(excess.max()) <= 0, (
+        f"element {worst}: got {float(a.reshape(-1)[worst])!r}, want {float(b.reshape(-1)[worst])!r} "
+        f"(rtol {rtol}, floor {afloor} * rms {rms:.4g})")

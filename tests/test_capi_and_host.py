@@ -61,6 +61,27 @@ def test_capi_argument_validation_without_gpu():
     assert lib.advhip_maxpool3d_f32(None, None, 1, 1, 2, 3, 3, 2, 3, 3, 2, 2, 2, None) == -1
 
 
+def test_uninstantiated_algo_ids_are_rejected_without_gpu():
+    """Ids inside a family's numeric range that have no kernel (DMA 69, DMA4 97/101-104, split-bf16 129-132/135/136,
+    DMA2 165, and anything outside every family) must be an error, never a silent no-op (host-side query only)."""
+    import ctypes as C
+
+    from anomaly_detection_on_video_amd import _lib
+
+    lib = _lib.load()
+    ok = set([0]) | set(_lib.IGEMM_ALGOS) | set(_lib.FAST_ALGOS) | set(_lib.DMA_ALGOS) | set(_lib.DMA4_ALGOS) | set(_lib.BF16X3_ALGOS) | set(_lib.DMA2_ALGOS)
+    for algo in range(0, 200):
+        d = _lib.ConvDesc(2, 64, 4, 13, 11, 128, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1, algo, 1)
+        rc = lib.advhip_conv3d_workspace_bytes(C.byref(d))
+        if algo in ok:
+            assert rc == 0, (algo, lib.advhip_last_error())
+        else:
+            assert rc == -1, algo
+            assert b"not instantiated" in lib.advhip_last_error(), (algo, lib.advhip_last_error())
+    for algo in (69, 97, 101, 104, 129, 132, 135, 136, 165):
+        assert algo not in ok
+
+
 def test_product_ops_refuse_cpu_tensors():
     from anomaly_detection_on_video_amd import _lib, mil_ops, ops
 
