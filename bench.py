@@ -35,17 +35,63 @@ def metric_name() -> str:
         return "16-frame 224² RGB clips/sec (I3D extract→MIL score), 1/2/4/8 GPU + %MFMA-peak"
 
 
+TRAFFIC_PROFILE = "profiles/traffic.json"  # written by tools/summarize_prof.py from the PMC passes of THIS command
+
+
 def measured_traffic(batch: int):
-    """HBM bytes per launch set from the committed PMC passes of this same command
+    """(HBM bytes per launch set, source) from the committed PMC passes of this same command
     (`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, separate passes; FETCH_SIZE doubled per the
-    gfx950 correction; profiles/r01_final_summary.md).  Counters cannot be read from inside the
-    process, so this is the profiled value for the benchmarked batch, else null."""
+    gfx950 correction).  Counters cannot be read from inside the process, so this is the profiled value for the
+    benchmarked batch -- with the profile file, the commit it was taken at and whether the kernels have changed
+    since (then it is stale and says so) -- else null."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_final_traffic.json")) as f:
+        with open(os.path.join(ROOT, TRAFFIC_PROFILE)) as f:
             t = json.load(f)
-        return float(t["conv"]["bytes_corrected"]) if batch == 32 else None
+        if batch != int(t.get("batch", 32)):
+            return None, None
+        src = {"file": TRAFFIC_PROFILE, "commit": t.get("commit"), "kernels_sha16": t.get("kernels_sha16"),
+               "stale": t.get("kernels_sha16") != kernels_sha16()}
+        return float(t["conv"]["bytes_corrected"]), src
     except Exception:
-        return None
+        return None, None
+
+
+def kernels_sha16() -> str:
+    """Hash of the kernel sources + tuned table: a traffic profile is only as fresh as these."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    pkg = os.path.join(ROOT, "anomaly_detection_on_video_amd")
+    for path in sorted(glob.glob(os.path.join(pkg, "csrc", "*.hip")) + glob.glob(os.path.join(pkg, "csrc", "*.h")) +
+                       [os.path.join(pkg, "tuned", "gfx950.json"), os.path.join(pkg, "i3d.py"), os.path.join(pkg, "pipeline.py")]):
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` outside torchrun: start the N rank processes (one per GPU) through
+    torch.distributed.run and relay rank 0's JSON line.  Called BEFORE this process has touched the GPU (a process
+    that has initialised HIP must never exec / be replaced; the children are fresh processes)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if proc.returncode != 0 or len(lines) != 1:
+        sys.stderr.write(proc.stdout[-4000:])
+        sys.stderr.write(f"\nbench.py: {n}-rank launch failed (exit {proc.returncode}, {len(lines)} result lines)\n")
+        return proc.returncode or 1
+    print(lines[0], flush=True)
+    return 0
 
 
 def cpu_baseline(budget_s: float = 12.0):
@@ -102,7 +148,13 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="crop-clips per GPU per step (BASELINE config 2: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--h2d", action="store_true", help="also time a PCIe-inclusive variant (host fp32 input each step)")
+    ap.add_argument("--sustain-s", type=float, default=3.0, help="seconds of back-to-back steps after the K timed ones (the `sustained` record: DVFS shows here)")
+    ap.add_argument("--no-mgfn-train", action="store_true", help="skip the MGFN training-step record (config 4)")
+    ap.add_argument("--dry-run", action="store_true", help="rendezvous only (gloo, no GPU): checks the rank launch + result relay")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:  # plain `python bench.py --gpus N`: be our own launcher
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     from anomaly_detection_on_video_amd import dist as adist
     from anomaly_detection_on_video_amd.i3d import I3Res50
@@ -112,10 +164,16 @@ def main():
 
     rank, local_rank, world = adist.env_world()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with python -m torch.distributed.run "
-                             f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    if args.dry_run:  # no GPU call anywhere on this path
+        adist.init_process_group("gloo")
+        n = torch.ones(1)
+        if world > 1:
+            torch.distributed.all_reduce(n)
+            torch.distributed.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": metric_name(), "dry_run": True, "n_gpus": int(n.item()), "steps": args.steps, "warmup": args.warmup}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
     # ADV_BENCH_SHARE_GPU=1 (rehearsal only): every rank uses cuda:0 and the collective runs over gloo,
@@ -190,6 +248,56 @@ def main():
         conv_ms_avg = sum(conv_ms) / len(conv_ms)
     achieved = args.batch * GFLOP_PER_CLIP / conv_ms_avg  # GFLOP/ms == TFLOP/s
 
+    # sustained: >= sustain_s seconds of back-to-back steps right after the timed ones (short runs hold a higher
+    # clock than the chip sustains; this record shows the difference instead of hiding it).  Same step count on
+    # every rank (derived from the max-reduced time), same barrier / synchronize bracket.
+    sustained = None
+    if args.sustain_s > 0:
+        n_sus = max(args.steps, int(args.sustain_s / (elapsed / args.steps)) + 1)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_sus):
+            stream.step_async(x)
+        stream.drain()
+        barrier()
+        sus = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([sus], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            sus = float(t.item())
+        sus_clips = args.batch * world * n_sus / sus
+        sustained = {"steps": n_sus, "seconds": round(sus, 3), "clips_per_s": round(sus_clips, 2),
+                     "ms_per_step": round(sus / n_sus * 1e3, 4),
+                     "frac_of_mfma_peak_whole_step": round(sus_clips / world * GFLOP_PER_CLIP / 1e3 / PEAK_F32_MFMA_TFLOPS, 4)}
+
+    # BASELINE config 4: one MGFN training step (32,10,32,2049): forward + 4 losses + backward + Adam, rank 0 at N=1
+    mgfn_train = None
+    if world == 1 and not args.no_mgfn_train:
+        scorer.train()
+        opt = torch.optim.Adam(scorer.parameters(), lr=1e-3, weight_decay=5e-4)
+        vb = torch.rand(32, 10, 32, 2048, device=dev, generator=gen) * 3
+        vb = torch.cat([vb, vb.norm(dim=3, keepdim=True)], dim=3)
+        al, nl = torch.ones(16, device=dev), torch.zeros(16, device=dev)
+
+        def train_step():
+            opt.zero_grad(set_to_none=True)
+            scorer(video=vb, abnormal_labels=al, normal_labels=nl).loss.backward()
+            opt.step()
+
+        for _ in range(3):
+            train_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            train_step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t1) / 10 * 1e3
+        tflop = 3 * 2 * 293.3e9 / 1e12  # forward 293.3 GMAC, backward = 2 x forward
+        mgfn_train = {"workload": "run.py MIL scorer + losses, fwd+bwd+Adam, (32,10,32,2049) fp32, 1 GPU", "ms_per_step": round(ms, 3),
+                      "tflop_per_step": round(tflop, 3), "achieved_tflops": round(tflop / ms * 1e3, 2),
+                      "frac_of_f32_mfma_peak": round(tflop / ms * 1e3 / PEAK_F32_MFMA_TFLOPS, 4)}
+        scorer.eval()
+
     h2d = h2d_u8 = None
     if args.h2d and world == 1:  # single-process extra; with N > 1 a rank-0-only step would leave the collective hanging
         # host buffers every step: the copy (and the uint8 pre-processing) is issued on the step's lane, so PCIe
@@ -214,6 +322,7 @@ def main():
         h2d_u8 = timed(xu, lambda h: mil_ops.normalize_permute_u8(h.to(dev, non_blocking=True)))
 
     if rank == 0:
+        traffic, traffic_src = measured_traffic(args.batch)
         total_clips = args.batch * world * args.steps
         out = {
             "metric": metric_name(),
@@ -238,14 +347,19 @@ def main():
             },
             "roofline": {
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(args.batch),
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                 "traffic_unit": "bytes per launch set (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes in profiles/)",
+                "traffic_source": traffic_src,
                 "kernel": "conv3d fp32-MFMA stack (53 launches per step on rank 0)" if not overlapped else
                 f"conv3d fp32-MFMA stack ({53 * n_streams} launches per step on rank 0; steps alternate between {stream.lanes} HIP stream lanes, "
                 f"batch split over {n_streams} stream(s) per step; time = first start .. last end over the K steps / K, pools + scoring included)",
                 "flop_per_launch_set": args.batch * GFLOP_PER_CLIP * 1e9, "avg_ms_per_launch_set": round(conv_ms_avg, 4),
             },
         }
+        if sustained is not None:
+            out["sustained"] = sustained
+        if mgfn_train is not None:
+            out["mgfn_train_step"] = mgfn_train
         if h2d is not None:
             out["pcie_inclusive_clips_per_s"] = round(h2d, 2)
             out["pcie_inclusive_uint8_clips_per_s"] = round(h2d_u8, 2)

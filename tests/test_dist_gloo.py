@@ -64,3 +64,27 @@ def test_sharded_rows_match_single_process(world, n_units):
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, n_units, out), nprocs=world, join=True)
     assert dict(out) == {r: True for r in range(world)}
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` as the driver calls it (no torchrun around it, WORLD_SIZE unset): bench.py starts N
+    rank processes itself before touching the GPU and relays rank 0's single JSON line; a failing rank makes the
+    launcher exit non-zero.  --dry-run keeps the ranks off the GPU (gloo rendezvous only)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["dry_run"] is True
+    if not torch.cuda.is_available():  # the real path needs a GPU: every rank exits non-zero, so must the launcher
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode != 0 and not p.stdout.strip()
+        assert "needs an AMD GPU" in p.stderr

@@ -70,6 +70,7 @@ def main():
         for line in open(a.bench):
             if line.startswith('{"metric"'):
                 bench = json.loads(line)
+    bench_line = bench
     out = ["# rocprofv3 summary of `bench.py` (%s)\n" % os.path.basename(a.out)]
     if bench:
         out.append("bench line under the profiler: value %.1f clips/s, %.3f ms/step, conv stack (HIP events) %.3f ms -> %.1f TFLOP/s\n"
@@ -110,6 +111,23 @@ def main():
             res[fam] = {"fetch_kb": f, "write_kb": w, "bytes_corrected": 2 * f * 1024 + w * 1024}
         with open(a.out + "_traffic.json", "w") as fp:
             json.dump(res, fp, indent=1)
+        # the copy bench.py reads for roofline.traffic: tagged with the commit and a hash of the kernel sources it was
+        # profiled at, so a later bench line can say whether the number is stale (bench.py:measured_traffic)
+        import subprocess
+        import sys
+
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        import bench
+
+        try:
+            commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+        except Exception:
+            commit = None
+        tagged = dict(res, batch=(bench_line or {}).get("config", {}).get("local_batch", 32), commit=commit,
+                      kernels_sha16=bench.kernels_sha16(), profile=os.path.basename(a.out) + "_summary.md", forwards=nf)
+        with open(os.path.join(root, bench.TRAFFIC_PROFILE), "w") as fp:
+            json.dump(tagged, fp, indent=1)
     if a.mfma:
         # matrix-pipe utilisation from counters: SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of all
         # 1024 SIMDs, GRBM_GUI_ACTIVE the active cycles of the 8 XCDs (MI355X_MICROARCH.md counters).
