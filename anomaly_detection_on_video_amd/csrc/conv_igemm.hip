@@ -76,8 +76,13 @@ struct ConvArgs {
   int THWo, HWo, HW, THW;
   int tiles_m, tiles_n;
   int relu, vw;
-  int splits;         // 1 = fused epilogue; >1 = raw partial sums, reduced by splitk_reduce_kernel
-  long long slab;     // elements per split-K slab
+  int splits;         // 1 = fused epilogue; >1 = K cut into that many slices
+  long long slab;     // elements per split-K slab (two-launch form: raw partial sums in y, reduced by splitk_reduce_kernel)
+  // in-kernel reduction (LDS-DMA kernels): every (tile, slice) workgroup publishes its partial tile, draws a ticket on the
+  // tile's arrival counter, and the workgroup that arrives last sums the slices in slice order and runs the fused epilogue
+  float* part;        // [tiles][splits][BM*BN] partial tiles, fragment-major (nullptr = two-launch form)
+  unsigned* cnt;      // [tiles] arrival counters, zeroed by a memset node ahead of the launch
+  unsigned part_bytes;
   // fast kernel only
   int kt_, kh_, kw_;  // kernel extents (tap decode)
   int pad_off;        // pt*HW + ph*W + pw: makes every per-lane window origin offset non-negative
@@ -127,14 +132,13 @@ struct IgemmCfg {
 //   m = m0 + wm*WM + FM*(4*lg + r) + jm,   n = n0 + wn*WN + FN*li + jn
 template <int BM, int BN, int BK>
 __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[BM / 32][BN / 32], float* smem, int split,
-                                               int m0, int n0, int wave, int lane) {
+                                               int m0, int n0, int wave, int lane, bool fused) {
   using Cfg = IgemmCfg<BM, BN, BK>;
   constexpr int FM = Cfg::FM, FN = Cfg::FN;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lg = lane >> 4;
   const int b_col = wn * Cfg::WN + FN * li;
-  const bool fused = a.splits == 1;
-  float* __restrict__ yout = a.y + (size_t)split * a.slab;
+  float* __restrict__ yout = fused ? a.y : a.y + (size_t)split * a.slab;
   if (a.vw == 4) {
     // Coalesced path (THWo % 4 == 0): each wave transposes its tile through LDS, one fragment
     // column (16 channels x WM positions) at a time, so that global stores / residual loads are
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_f32_kernel(const ConvArgs a)
     __syncthreads();
   }
 
-  igemm_epilogue<BM, BN, BK>(a, acc, smem, split, m0, n0, wave, lane);
+  igemm_epilogue<BM, BN, BK>(a, acc, smem, split, m0, n0, wave, lane, a.splits == 1);
 }
 
 // ================================================================================================
@@ -544,7 +548,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_fast_kernel(const ConvArgs a
     store_tiles(cur ^ 1);
     __syncthreads();
   }
-  igemm_epilogue<BM, BN, BK>(a, acc, smem, split, m0, n0, wave, lane);
+  igemm_epilogue<BM, BN, BK>(a, acc, smem, split, m0, n0, wave, lane, a.splits == 1);
 }
 
 // ================================================================================================
@@ -787,7 +791,53 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
     stage = stage == NS - 1 ? 0 : stage + 1;
   }
   __syncthreads();  // every wave is done with the ring before the epilogue reuses it as staging
-  igemm_epilogue<BM, BN, BK>(a, acc, smem, split, m0, n0, wave, lane);
+  if (a.splits > 1) {  // the launcher always gives this kernel family a partial-tile workspace
+    // ---- in-kernel split-K reduction (cdna_hip_programming.md section 5, "In-launch split-K reduction", write-through form)
+    // publish: thread tid owns float4 (i*FN+j) of its accumulators at [(i*FN+j)*256 + tid] of the (tile, slice) block:
+    // whole 16-byte sc1 (write-through) stores, 4 KiB contiguous per store instruction of the workgroup
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    const auto rp = __builtin_amdgcn_make_buffer_rsrc(a.part, 0, a.part_bytes, 0x00020000);
+    constexpr unsigned TILE_BYTES = BM * BN * 4;
+    const unsigned my = (unsigned)(L * a.splits + split) * TILE_BYTES + (unsigned)tid * 16u;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rp, my + (unsigned)(i * FN + j) * 4096u, 0, 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains its write-through stores ...
+    __syncthreads();                                   // ... before ONE lane signals for all of them
+    unsigned* flag = reinterpret_cast<unsigned*>(smem);
+    if (tid == 0) *flag = __hip_atomic_fetch_add(a.cnt + L, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool last = *flag == (unsigned)(a.splits - 1);
+    __syncthreads();  // the flag word is staging space again below
+    if (!last) return;
+    // the last arriver: every slice of this tile has been published (write-through, drained before its ticket).  sc1
+    // loads bypass this CU's L1 (never refreshed by other CUs' stores); sum in slice order -> run-to-run bit-identical
+    // (in batches of G float4 per thread: the sums must not cost the main loop registers -- the occupancy target above
+    // is what keeps the matrix pipe busy -- so at most G loads per lane are in flight, one slice at a time)
+    const unsigned t0 = (unsigned)(L * a.splits) * TILE_BYTES + (unsigned)tid * 16u;
+    constexpr int NV = FM * FN, G = NV < 4 ? NV : 4;
+    auto at = [&](int v) -> f32x4& { return acc[v / FN][v % FN]; };
+#pragma unroll
+    for (int g0 = 0; g0 < NV; g0 += G) {
+#pragma unroll
+      for (int v = 0; v < G; ++v)
+        at(g0 + v) = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, t0 + (unsigned)(g0 + v) * 4096u, 0, 16));
+#pragma unroll 1
+      for (int sl = 1; sl < a.splits; ++sl) {
+        const unsigned ts = t0 + (unsigned)sl * TILE_BYTES;
+        f32x4 t[G];
+#pragma unroll
+        for (int v = 0; v < G; ++v)
+          t[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, ts + (unsigned)(g0 + v) * 4096u, 0, 16));
+#pragma unroll
+        for (int v = 0; v < G; ++v) at(g0 + v) += t[v];
+      }
+    }
+  }
+  // (one epilogue call site: a second inlined copy costs ~25 VGPRs and with them a resident workgroup per CU)
+  igemm_epilogue<BM, BN, BK>(a, acc, smem, 0, m0, n0, wave, lane, true);
 }
 
 // ================================================================================================
@@ -960,7 +1010,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(const ConvArgs
     if (more) store_tile();
     __syncthreads();
   }
-  igemm_epilogue<BM, BN, BK>(a, acc, reinterpret_cast<float*>(smem), split, m0, n0, wave, lane);
+  igemm_epilogue<BM, BN, BK>(a, acc, reinterpret_cast<float*>(smem), split, m0, n0, wave, lane, a.splits == 1);
 }
 
 // fp32 weights (Cout, K) (torch layout: K = (ci, dt, dh, dw) contiguous) -> [2][Cout][Kpad] bf16: hi image, lo image
@@ -1214,6 +1264,27 @@ static Geometry geometry(const advhip_conv3d_desc* d) {
 }
 }  // namespace advhip
 
+namespace advhip {
+// the LDS-DMA kernel families reduce split-K partials inside the launch (no second kernel)
+static bool reduces_in_kernel(int algo) {
+  return (algo >= ADVHIP_ALGO_DMA_BASE && algo < ADVHIP_ALGO_BF16X3_BASE) || algo >= ADVHIP_ALGO_DMA2_BASE;
+}
+// Split-K workspace: two-launch form = [splits][M*Cout] slabs in y's layout; in-kernel form = [tiles] arrival counters
+// (padded to 256 bytes) followed by [tiles][splits][BM*BN] fragment-major partial tiles.
+struct SplitLayout {
+  int64_t cnt_bytes, part_bytes;
+  int64_t total() const { return cnt_bytes + part_bytes; }
+};
+static SplitLayout split_layout(const advhip_conv3d_desc* d, const Geometry& g, const Choice& c) {
+  if (c.splits <= 1) return {0, 0};
+  if (!reduces_in_kernel(c.algo)) return {0, (int64_t)c.splits * g.M * d->Cout * (int64_t)sizeof(float)};
+  int BM, BN, BK;
+  tile_of(c.algo, &BM, &BN, &BK);
+  const int64_t tiles = ((g.M + BM - 1) / BM) * (d->Cout / BN);
+  return {(tiles * 4 + 255) / 256 * 256, tiles * c.splits * BM * BN * (int64_t)sizeof(float)};
+}
+}  // namespace advhip
+
 extern "C" int64_t advhip_conv3d_workspace_bytes(const advhip_conv3d_desc* d) {
   if (validate(d)) return -1;
   const Geometry g = geometry(d);
@@ -1222,7 +1293,7 @@ extern "C" int64_t advhip_conv3d_workspace_bytes(const advhip_conv3d_desc* d) {
     set_error("conv3d: algo %d is not instantiated in this library", c.algo);
     return -1;
   }
-  return c.splits > 1 ? (int64_t)c.splits * g.M * d->Cout * (int64_t)sizeof(float) : 0;
+  return split_layout(d, g, c).total();
 }
 
 extern "C" int advhip_conv3d_bn_act_f32(const advhip_conv3d_desc* d, const float* x, const float* w_packed,
@@ -1275,7 +1346,7 @@ extern "C" int advhip_conv3d_bn_act_strided_f32(const advhip_conv3d_desc* d, con
   a.vw = aligned_to(4) ? 4 : (aligned_to(2) ? 2 : 1);
 
   Choice c = choose(d, M, g.Kpad);
-  if (ybs != y_dense) c.splits = 1;  // the split-K reduce pass writes a dense y
+  if (ybs != y_dense && !reduces_in_kernel(c.algo)) c.splits = 1;  // the separate split-K reduce pass writes a dense y
   int BM, BN, BK;
   tile_of(c.algo, &BM, &BN, &BK);
   ADVHIP_REQUIRE(instantiated(c.algo), "conv3d: algo %d is not instantiated in this library", c.algo);
@@ -1294,12 +1365,21 @@ extern "C" int advhip_conv3d_bn_act_strided_f32(const advhip_conv3d_desc* d, con
   a.slab = M * d->Cout;
   const int nk = (g.Kpad + BK - 1) / BK;
   ADVHIP_REQUIRE(c.splits >= 1 && c.splits <= nk && c.splits <= 64, "conv3d: bad split count %d (k-tiles %d)", c.splits, nk);
+  a.part = nullptr; a.cnt = nullptr; a.part_bytes = 0;
+  const SplitLayout lay = split_layout(d, g, c);
   if (c.splits > 1) {
-    const int64_t need = (int64_t)c.splits * a.slab * (int64_t)sizeof(float);
-    ADVHIP_REQUIRE(workspace != nullptr && workspace_bytes >= need,
+    ADVHIP_REQUIRE(workspace != nullptr && workspace_bytes >= lay.total(),
                    "conv3d: split-K needs a %lld-byte workspace (got %lld); query advhip_conv3d_workspace_bytes",
-                   (long long)need, (long long)workspace_bytes);
-    a.y = reinterpret_cast<float*>(workspace);
+                   (long long)lay.total(), (long long)workspace_bytes);
+    if (reduces_in_kernel(c.algo)) {
+      ADVHIP_REQUIRE(lay.part_bytes < 0xF0000000ll && (uintptr_t)workspace % 16 == 0,
+                     "conv3d: split-K partial tiles need a 16-byte aligned workspace below 3.75 GiB (%lld bytes)", (long long)lay.part_bytes);
+      a.cnt = reinterpret_cast<unsigned*>(workspace);
+      a.part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + lay.cnt_bytes);
+      a.part_bytes = (unsigned)lay.part_bytes;
+    } else {
+      a.y = reinterpret_cast<float*>(workspace);
+    }
   }
   a.tiles_m = (int)((M + BM - 1) / BM);
   a.tiles_n = d->Cout / BN;
@@ -1307,6 +1387,9 @@ extern "C" int advhip_conv3d_bn_act_strided_f32(const advhip_conv3d_desc* d, con
   a.dSplits = FastDiv::make((unsigned)c.splits);
   dim3 grid((unsigned)(a.tiles_m * a.tiles_n * c.splits));
   hipStream_t st = (hipStream_t)stream;
+  if (a.cnt != nullptr) {  // arrival counters start every launch at zero (a memset node: graph-capturable, replayed first)
+    if (hipMemsetAsync(a.cnt, 0, (size_t)lay.cnt_bytes, st) != hipSuccess) return check_launch("conv3d split-K counters");
+  }
   // BK = 32 needs Kpad % 32 == 0: the packed weights are padded to 16 rows only, but the k-table
   // marks rows >= K invalid and the weight rows read beyond Kpad must exist -> require it.
   if (BK == 32) ADVHIP_REQUIRE(g.Kpad % 32 == 0, "conv3d: BK=32 variants need K padded to 32 (K=%d)", g.K);
@@ -1378,7 +1461,7 @@ extern "C" int advhip_conv3d_bn_act_strided_f32(const advhip_conv3d_desc* d, con
       return ADVHIP_EINVAL;
   }
   if (int rc = check_launch("conv3d_igemm")) return rc;
-  if (c.splits > 1) {
+  if (c.splits > 1 && a.part == nullptr) {
     const long long total = a.slab;
     const int vec4 = a.vw == 4 ? 1 : 0;  // rows, slabs, residual and y all 16-byte aligned
     const long long work = vec4 ? total / 4 : total;
