@@ -82,6 +82,10 @@ SIGNATURES = {
     "advhip_conv3d_workspace_bytes": (_L, [C.POINTER(ConvDesc)]),
     "advhip_conv3d_bn_act_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "advhip_conv3d_bn_act_strided_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _L, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P]),
+    "advhip_conv3d_pool_out_dims": (C.c_int, [C.POINTER(ConvDesc)] + [_I] * 6 + [C.POINTER(_I)] * 3),
+    "advhip_conv3d_relu_maxpool233_workspace_bytes": (_L, [C.POINTER(ConvDesc)]),
+    "advhip_conv3d_bn_relu_maxpool233_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P]),
+    "advhip_conv3d_bn_act_maxpool211_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _L, _P, _P, _P, _P, _P, _P, _L, _P]),
     "advhip_maxpool3d_f32": (C.c_int, [_P, _P] + [_I] * 11 + [_P]),
     "advhip_maxpool3d_strided_f32": (C.c_int, [_P, _P, _L] + [_I] * 11 + [_P]),
     "advhip_global_avgpool_f32": (C.c_int, [_P, _P, _L, _I, _P]),

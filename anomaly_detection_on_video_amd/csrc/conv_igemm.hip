@@ -80,6 +80,10 @@ struct ConvArgs {
   long long slab;     // elements per split-K slab (two-launch form: raw partial sums in y, reduced by splitk_reduce_kernel)
   // in-kernel reduction (LDS-DMA kernels): every (tile, slice) workgroup publishes its partial tile, draws a ticket on the
   // tile's arrival counter, and the workgroup that arrives last sums the slices in slice order and runs the fused epilogue
+  // brick-ordered m (pooling epilogues): an m-tile is a 2 x BH x BW brick of output positions (t, h, w) of one sample
+  int nbh, nbw;       // bricks per sample along h and w (nbt = pooled T)
+  int Tp;             // pooled temporal extent (EPI_TPOOL output)
+  FastDiv dNb, dNbhw, dNbw;
   float* part;        // [tiles][splits][BM*BN] partial tiles, fragment-major (nullptr = two-launch form)
   unsigned* cnt;      // [tiles] arrival counters, zeroed by a memset node ahead of the launch
   unsigned part_bytes;
@@ -551,6 +555,126 @@ __global__ __launch_bounds__(256) void conv3d_igemm_fast_kernel(const ConvArgs a
   igemm_epilogue<BM, BN, BK>(a, acc, smem, split, m0, n0, wave, lane, a.splits == 1);
 }
 
+// Epilogue forms of the LDS-DMA kernel.  The pooling forms fuse the nn.MaxPool3d that follows the conv in
+// I3Res50.forward_single (src/i3d.py:303-309) into the conv launch; they order m in bricks (see brick_* below).
+enum : int {
+  EPI_STD = 0,      // y = act(conv * scale + shift (+ res)), NCDHW
+  EPI_TPOOL = 2,    // + MaxPool3d k(2,1,1) s(2,1,1): brick 2(t) x BM/2 flattened (h,w) of a 1x1x1 conv; exact, no halo
+  EPI_POOL233 = 3,  // + ReLU + MaxPool3d k(2,3,3) s(2,2,2) p0: brick 2(t) x 4(h) x BM/8(w); per-brick maxima of every pooling
+                    //   window the brick touches go to a partial tensor, stem_pool_merge_kernel maxes the 1/2/4 partials
+};
+
+// ---- pooling epilogues on brick-ordered tiles (128 x 64 tile, 2 x 2 waves) ----------------------------------------------
+// Wave (wm, wn) holds t plane wm of the brick (64 positions: BH rows of BW outputs) for 32 channels; accumulator element
+// acc[i][jn][r] of lane (li, lg) sits at position 16*lg + 4*r + i of the plane, channel n0 + 2*(16*wn + li) + jn.  One
+// fragment column jn at a time, all four waves lay their values out in LDS as [32 channels][2 planes x 64 positions]
+// (scale/shift applied; the stem form also applies ReLU and zeroes positions outside the tensor -- every real value is
+// >= 0 after ReLU, so 0 is neutral for the maxima), then the 256 threads pool from LDS with coalesced global accesses.
+constexpr int POOL_SLOTS = 27;  // per brick and channel: 3 row slots x 9 column slots (see brick_epilogue, EPI_POOL233)
+
+template <int BM, int BN, int BK, int EPI>
+__device__ __forceinline__ void brick_epilogue(const ConvArgs& a, f32x4 (&acc)[BM / 32][BN / 32], float* smem, int tile_m,
+                                               int tile_n, int n0, int bk_b, int bk_t, int bk_h, int bk_w, int wave, int lane,
+                                               int tid) {
+  constexpr int FM = BM / 32, FN = BN / 32, RS = BM + 4, CH = BN / FN;  // CH channels per pass
+  static_assert(FM == 4 && FN == 2, "128 x 64 tile");
+  constexpr int BH = EPI == EPI_POOL233 ? 4 : 1, BW = BM / (2 * BH);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lg = lane >> 4;
+  const int c_w = wn * 16 + li;  // this lane's channel row of the pass
+#pragma unroll
+  for (int jn = 0; jn < FN; ++jn) {
+    const int n_w = n0 + 2 * c_w + jn;
+    const float sc = a.scale[n_w], sf = a.shift[n_w];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = acc[i][jn][r] * sc + sf;
+      if constexpr (EPI == EPI_POOL233) {
+        // plane position 16*lg + 4*r + i -> (dh, dw) = (pos / BW, pos % BW)
+        const int ot = bk_t * 2 + wm;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int pos = 16 * lg + 4 * r + i;
+          const bool ok = ot < a.To && bk_h * BH + pos / BW < a.Ho && bk_w * BW + pos % BW < a.Wo;
+          v[i] = ok ? fmaxf(v[i], 0.f) : 0.f;
+        }
+      }
+      *reinterpret_cast<float4*>(&smem[c_w * RS + wm * 64 + 16 * lg + 4 * r]) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+    if constexpr (EPI == EPI_TPOOL) {
+      // y[b, n, tp, p] = max_t relu(conv[b, n, 2 tp + t, p] (+ res)): thread = one position p of the brick, 8 channels
+      const int pw = tid % BW, c0 = tid / BW;  // BW = 64 positions, 4 channel groups
+      const int ow = bk_w * BW + pw;
+      if (ow < a.Wo) {
+#pragma unroll
+        for (int i = 0; i < CH / 4; ++i) {
+          const int c = c0 + 4 * i;
+          const int n = n0 + 2 * c + jn;
+          float v0 = smem[c * RS + pw], v1 = smem[c * RS + 64 + pw];
+          if (a.res) {
+            const size_t o = ((size_t)bk_b * a.Cout + n) * a.THWo + (size_t)(bk_t * 2) * a.HWo + ow;
+            v0 += a.res[o];
+            v1 += a.res[o + a.HWo];
+          }
+          if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+          a.y[(size_t)bk_b * a.y_bstride + ((size_t)n * a.Tp + bk_t) * a.HWo + ow] = fmaxf(v0, v1);
+        }
+      }
+    } else {
+      // every pooling window (2 t) x (rows 2hp..2hp+2) x (cols 2wp..2wp+2) that meets the brick gets the maximum over the
+      // part of it inside the brick.  Brick rows 4k..4k+3: slot 0 = window hp=2k-1 (row 0 only), slot 1 = hp=2k (rows 0-2,
+      // complete), slot 2 = hp=2k+1 (rows 2-3).  Brick columns 16j..16j+15: slot 0 = wp=8j-1 (column 0), slots 1..7 =
+      // wp=8j..8j+6 (complete), slot 8 = wp=8j+7 (columns 14-15).
+      float* __restrict__ P = a.y + ((size_t)(tile_m * a.tiles_n + tile_n) * FN + jn) * (CH * POOL_SLOTS);
+      for (int o = tid; o < CH * POOL_SLOTS; o += 256) {
+        const int c = o / POOL_SLOTS, s = o - c * POOL_SLOTS;
+        const int rs = s / 9, cs = s - rs * 9;
+        const int h0 = rs == 2 ? 2 : 0, h1 = rs == 0 ? 0 : (rs == 1 ? 2 : 3);
+        const int w0 = cs == 0 ? 0 : 2 * (cs - 1), w1 = cs == 0 ? 0 : (cs == 8 ? 15 : 2 * cs);
+        float m = 0.f;
+        for (int t = 0; t < 2; ++t)
+          for (int h = h0; h <= h1; ++h)
+            for (int w = w0; w <= w1; ++w) m = fmaxf(m, smem[c * RS + t * 64 + h * BW + w]);
+        P[o] = m;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Pooled stem output from the per-brick partial maxima: y[b, n, tp, hp, wp] = max over the 1, 2 or 4 bricks the window meets.
+__global__ void stem_pool_merge_kernel(const float* __restrict__ P, float* __restrict__ y, int Cout, int Tp, int Hp, int Wp,
+                                       int nbh, int nbw, int tiles_n, long long total, long long per_sample, long long ypad) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int wp = (int)(i % Wp);
+    long long r = i / Wp;
+    const int hp = (int)(r % Hp);
+    r /= Hp;
+    const int tp = (int)(r % Tp);
+    r /= Tp;
+    const int n = (int)(r % Cout);
+    const int b = (int)(r / Cout);
+    // row contributions (brick, slot): hp even -> complete in brick hp/2; hp odd -> rows 2-3 of brick (hp-1)/2 + row 0 of the next
+    int hb[2], hs[2], nh = 1;
+    if ((hp & 1) == 0) { hb[0] = hp >> 1; hs[0] = 1; }
+    else { hb[0] = hp >> 1; hs[0] = 2; hb[1] = (hp >> 1) + 1; hs[1] = 0; nh = 2; }
+    int wb[2], ws[2], nw = 1;
+    if ((wp & 7) != 7) { wb[0] = wp >> 3; ws[0] = 1 + (wp & 7); }
+    else { wb[0] = wp >> 3; ws[0] = 8; wb[1] = (wp >> 3) + 1; ws[1] = 0; nw = 2; }
+    const int tile_n = n >> 6, nl = n & 63, jn = nl & 1, c = nl >> 1;
+    float m = 0.f;
+    for (int u = 0; u < nh; ++u)
+      for (int v = 0; v < nw; ++v) {
+        const long long tile_m = (((long long)b * Tp + tp) * nbh + hb[u]) * nbw + wb[v];
+        m = fmaxf(m, P[((tile_m * tiles_n + tile_n) * 2 + jn) * (32 * POOL_SLOTS) + c * POOL_SLOTS + hs[u] * 9 + ws[v]]);
+      }
+    y[i + (i / per_sample) * ypad] = m;
+  }
+}
+
 // ================================================================================================
 // LDS-DMA variant of the fast kernel: operand tiles go HBM/L2 -> LDS directly
 // (`buffer_load_dword ... lds` for the gathered A rows, `buffer_load_dwordx4 ... lds` for the packed
@@ -629,7 +753,7 @@ constexpr int dma_waves_per_simd() {
   return by_lds > 8 ? 8 : (by_lds < 1 ? 1 : by_lds);
 }
 
-template <int BM, int BN, int BK, bool CHECK, int NS = 3>
+template <int BM, int BN, int BK, bool CHECK, int NS = 3, int EPI = EPI_STD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dma_waves_per_simd<BM, BN, BK, NS>(), 8)))
 void conv3d_igemm_dma_kernel(const ConvArgs a) {
   using Cfg = IgemmCfg<BM, BN, BK>;
@@ -639,7 +763,11 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   static_assert(LB >= 1 && LA >= 1 && (NS - 2) * (LA + LB) <= 63, "tile / vmcnt budget");
   constexpr unsigned OOB = 0xFFFFFF00u;
   constexpr int RING = NS * D::STAGE;
-  constexpr int SMEM = RING > Cfg::ST_FLOATS ? RING : Cfg::ST_FLOATS;
+  constexpr int BRICK_FLOATS = EPI == EPI_STD ? 0 : (BN / Cfg::FN) * (BM + 4);  // one fragment column of every wave: [BN/FN channels][BM + 4]
+  constexpr int SMEM0 = RING > Cfg::ST_FLOATS ? RING : Cfg::ST_FLOATS;
+  constexpr int SMEM = SMEM0 > BRICK_FLOATS ? SMEM0 : BRICK_FLOATS;
+  static_assert(EPI == EPI_STD || (BM == 128 && BN == 64), "pooling epilogues: 128 x 64 tile (wave row = one t plane of the brick)");
+  constexpr int BRICK_H = EPI == EPI_POOL233 ? 4 : 1, BRICK_W = BM / (2 * BRICK_H);
 
   __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
@@ -668,15 +796,38 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   const int m = m0 + ml;
   unsigned vbase = OOB;
   unsigned vmask = 0;
-  if (m < a.M) {
-    const int b = (int)a.dTHWo.div((unsigned)m);
-    const int p = m - b * a.THWo;
-    const int ot = (int)a.dHWo.div((unsigned)p);
-    const int q = p - ot * a.HWo;
-    const int oh = (int)a.dWo.div((unsigned)q);
-    const int ow = q - oh * a.Wo;
-    const int it0 = ot * a.st - a.pt, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
-    vbase = (unsigned)(b * a.x_bstride + it0 * a.HW + ih0 * a.W + iw0 + a.pad_off) * 4u;
+  // output position of this thread's A column: (sample, ot, oh, ow)
+  int pb = 0, pot = 0, poh = 0, pow_ = 0;
+  bool pvalid;
+  int bk_b = 0, bk_t = 0, bk_h = 0, bk_w = 0;  // brick forms: sample and brick coordinates of this m-tile
+  if constexpr (EPI == EPI_STD) {
+    pvalid = m < a.M;
+    if (pvalid) {
+      pb = (int)a.dTHWo.div((unsigned)m);
+      const int p = m - pb * a.THWo;
+      pot = (int)a.dHWo.div((unsigned)p);
+      const int q = p - pot * a.HWo;
+      poh = (int)a.dWo.div((unsigned)q);
+      pow_ = q - poh * a.Wo;
+    }
+  } else {
+    // m-tile -> (sample, brick t, brick h, brick w); row ml of the tile -> position (dt, dh, dw) inside the brick, w fastest:
+    // a wave's 64 rows are one t plane of the brick, its LDS-DMA pieces BRICK_H row segments of BRICK_W outputs
+    bk_b = (int)a.dNb.div((unsigned)tile_m);
+    const int r1 = tile_m - bk_b * (int)a.dNb.d;
+    bk_t = (int)a.dNbhw.div((unsigned)r1);
+    const int r2 = r1 - bk_t * (int)a.dNbhw.d;
+    bk_h = (int)a.dNbw.div((unsigned)r2);
+    bk_w = r2 - bk_h * a.nbw;
+    pb = bk_b;
+    pot = bk_t * 2 + ml / (BRICK_H * BRICK_W);
+    poh = bk_h * BRICK_H + (ml / BRICK_W) % BRICK_H;
+    pow_ = bk_w * BRICK_W + ml % BRICK_W;
+    pvalid = pot < a.To && poh < a.Ho && pow_ < a.Wo;
+  }
+  if (pvalid) {
+    const int it0 = pot * a.st - a.pt, ih0 = poh * a.sh - a.ph, iw0 = pow_ * a.sw - a.pw;
+    vbase = (unsigned)(pb * a.x_bstride + it0 * a.HW + ih0 * a.W + iw0 + a.pad_off) * 4u;
     if constexpr (CHECK) {
       vmask = tap_bits(it0, a.kt_, a.T) | (tap_bits(ih0, a.kh_, a.H) << 10) | (tap_bits(iw0, a.kw_, a.W) << 20);
     }
@@ -835,6 +986,10 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
         for (int v = 0; v < G; ++v) at(g0 + v) += t[v];
       }
     }
+  }
+  if constexpr (EPI != EPI_STD) {
+    brick_epilogue<BM, BN, BK, EPI>(a, acc, smem, tile_m, tile_n, n0, bk_b, bk_t, bk_h, bk_w, wave, lane, tid);
+    return;
   }
   // (one epilogue call site: a second inlined copy costs ~25 VGPRs and with them a resident workgroup per CU)
   igemm_epilogue<BM, BN, BK>(a, acc, smem, 0, m0, n0, wave, lane, true);
@@ -1471,4 +1626,129 @@ extern "C" int advhip_conv3d_bn_act_strided_f32(const advhip_conv3d_desc* d, con
     return check_launch("splitk_reduce");
   }
   return ADVHIP_OK;
+}
+
+// ---- conv + max-pool in one launch (brick-ordered LDS-DMA kernel) ----------------------------------------------------
+namespace advhip {
+static int pool_out(int n, int k, int s) { return n >= k ? (n - k) / s + 1 : 0; }
+
+// shared argument set-up of the two pooling forms; `flat_hw`: present the (1x1x1, stride 1) conv as H = 1, W = H*W
+static int fill_pool_args(ConvArgs& a, const advhip_conv3d_desc* d, const Geometry& g, const float* x, int64_t x_batch_stride,
+                          const float* w_packed, const int32_t* ktab, const float* scale, const float* shift, bool flat_hw) {
+  a.x = x; a.w = w_packed; a.ktab = reinterpret_cast<const int4*>(ktab);
+  a.scale = scale; a.shift = shift; a.res = nullptr; a.y = nullptr;
+  a.B = d->B; a.Cin = d->Cin; a.T = d->T; a.Cout = d->Cout;
+  a.H = flat_hw ? 1 : d->H; a.W = flat_hw ? d->H * d->W : d->W;
+  a.st = d->st; a.sh = d->sh; a.sw = d->sw; a.pt = d->pt; a.ph = d->ph; a.pw = d->pw;
+  a.To = g.To; a.Ho = flat_hw ? 1 : g.Ho; a.Wo = flat_hw ? g.Ho * g.Wo : g.Wo;
+  const long long x_dense = (long long)d->Cin * d->T * d->H * d->W;
+  const long long xbs = x_batch_stride > 0 ? x_batch_stride : x_dense;
+  ADVHIP_REQUIRE(xbs >= x_dense, "conv3d+pool: x batch stride %lld smaller than one sample (%lld)", xbs, x_dense);
+  const long long in_elems = (long long)(d->B - 1) * xbs + x_dense;
+  ADVHIP_REQUIRE(fast_ok(d, in_elems, (long long)g.Kpad * d->Cout) && g.M * d->Cout < (1ll << 32) && in_elems < (1ll << 31),
+                 "conv3d+pool: tensor too large for 32-bit offsets");
+  a.M = (int)g.M;
+  a.x_bstride = (int)xbs;
+  a.Kpad = g.Kpad;
+  a.HWo = g.Ho * g.Wo; a.THWo = g.To * a.HWo;
+  a.HW = d->H * d->W; a.THW = d->T * a.HW;
+  a.relu = d->relu;
+  a.vw = 1;
+  a.dTHWo = FastDiv::make((unsigned)a.THWo); a.dHWo = FastDiv::make((unsigned)a.HWo); a.dWo = FastDiv::make((unsigned)a.Wo);
+  a.kt_ = d->kt; a.kh_ = d->kh; a.kw_ = d->kw;
+  a.pad_off = d->pt * d->H * d->W + d->ph * d->W + d->pw;
+  a.x_bytes = (unsigned)((in_elems + a.pad_off) * 4);
+  a.w_bytes = (unsigned)((long long)g.Kpad * d->Cout * 4);
+  a.splits = 1; a.slab = 0; a.part = nullptr; a.cnt = nullptr; a.part_bytes = 0;
+  a.tiles_n = d->Cout / 64;
+  a.dTilesN = FastDiv::make((unsigned)a.tiles_n);
+  a.dSplits = FastDiv::make(1u);
+  return ADVHIP_OK;
+}
+
+static void set_bricks(ConvArgs& a, int nbt, int nbh, int nbw) {
+  a.nbh = nbh; a.nbw = nbw;
+  a.dNb = FastDiv::make((unsigned)(nbt * nbh * nbw));
+  a.dNbhw = FastDiv::make((unsigned)(nbh * nbw));
+  a.dNbw = FastDiv::make((unsigned)nbw);
+  a.tiles_m = a.B * nbt * nbh * nbw;
+}
+}  // namespace advhip
+
+extern "C" int advhip_conv3d_pool_out_dims(const advhip_conv3d_desc* d, int32_t pkt, int32_t pkh, int32_t pkw, int32_t pst,
+                                           int32_t psh, int32_t psw, int32_t* Tp, int32_t* Hp, int32_t* Wp) {
+  if (int rc = validate(d)) return rc;
+  ADVHIP_REQUIRE(pkt > 0 && pkh > 0 && pkw > 0 && pst > 0 && psh > 0 && psw > 0, "conv3d+pool: bad pooling window");
+  const Geometry g = geometry(d);
+  if (Tp) *Tp = pool_out(g.To, pkt, pst);
+  if (Hp) *Hp = pool_out(g.Ho, pkh, psh);
+  if (Wp) *Wp = pool_out(g.Wo, pkw, psw);
+  return ADVHIP_OK;
+}
+
+extern "C" int64_t advhip_conv3d_relu_maxpool233_workspace_bytes(const advhip_conv3d_desc* d) {
+  if (validate(d)) return -1;
+  const Geometry g = geometry(d);
+  const int Tp = pool_out(g.To, 2, 2), Hp = pool_out(g.Ho, 3, 2), Wp = pool_out(g.Wo, 3, 2);
+  if (Tp <= 0 || Hp <= 0 || Wp <= 0) return 0;
+  const int64_t bricks = (int64_t)d->B * Tp * ((2 * Hp + 1 + 3) / 4) * ((2 * Wp + 1 + 15) / 16);
+  return bricks * d->Cout * POOL_SLOTS * (int64_t)sizeof(float);
+}
+
+extern "C" int advhip_conv3d_bn_relu_maxpool233_f32(const advhip_conv3d_desc* d, const float* x, int64_t x_batch_stride,
+                                                    const float* w_packed, const int32_t* ktab, const float* scale,
+                                                    const float* shift, float* y, int64_t y_batch_stride, void* workspace,
+                                                    int64_t workspace_bytes, void* stream) {
+  if (int rc = validate(d)) return rc;
+  ADVHIP_REQUIRE(x && w_packed && ktab && scale && shift && y, "conv3d+pool233: null pointer");
+  const Geometry g = geometry(d);
+  const int Tp = pool_out(g.To, 2, 2), Hp = pool_out(g.Ho, 3, 2), Wp = pool_out(g.Wo, 3, 2);
+  ADVHIP_REQUIRE(Tp > 0 && Hp > 0 && Wp > 0, "conv3d+pool233: conv output (%d,%d,%d) smaller than the (2,3,3) window", g.To, g.Ho, g.Wo);
+  const int64_t need = advhip_conv3d_relu_maxpool233_workspace_bytes(d);
+  ADVHIP_REQUIRE(workspace != nullptr && workspace_bytes >= need && need < 0xF0000000ll,
+                 "conv3d+pool233: needs a %lld-byte workspace (got %lld)", (long long)need, (long long)workspace_bytes);
+  const long long y_dense = (long long)d->Cout * Tp * Hp * Wp;
+  const long long ybs = y_batch_stride > 0 ? y_batch_stride : y_dense;
+  ADVHIP_REQUIRE(ybs >= y_dense, "conv3d+pool233: y batch stride %lld smaller than one pooled sample (%lld)", ybs, y_dense);
+  ConvArgs a;
+  if (int rc = fill_pool_args(a, d, g, x, x_batch_stride, w_packed, ktab, scale, shift, false)) return rc;
+  a.y = reinterpret_cast<float*>(workspace);  // per-brick partial maxima
+  a.y_bstride = 0; a.Tp = Tp; a.relu = 1;
+  const int nbh = (2 * Hp + 1 + 3) / 4, nbw = (2 * Wp + 1 + 15) / 16;
+  set_bricks(a, Tp, nbh, nbw);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
+  const bool nocheck = d->kt == 1 && d->kh == 1 && d->kw == 1 && d->pt == 0 && d->ph == 0 && d->pw == 0 && g.K == g.Kpad;
+  if (nocheck) hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, false, 2, EPI_POOL233>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, true, 2, EPI_POOL233>), grid, dim3(256), 0, st, a);
+  if (int rc = check_launch("conv3d+pool233")) return rc;
+  const long long total = (long long)d->B * y_dense;
+  const int mgrid = (int)std::min<long long>((total + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(stem_pool_merge_kernel, dim3(mgrid), dim3(256), 0, st, reinterpret_cast<const float*>(workspace), y, d->Cout,
+                     Tp, Hp, Wp, nbh, nbw, a.tiles_n, total, y_dense, ybs - y_dense);
+  return check_launch("stem_pool_merge");
+}
+
+extern "C" int advhip_conv3d_bn_act_maxpool211_f32(const advhip_conv3d_desc* d, const float* x, int64_t x_batch_stride,
+                                                   const float* w_packed, const int32_t* ktab, const float* scale,
+                                                   const float* shift, const float* residual, float* y,
+                                                   int64_t y_batch_stride, void* stream) {
+  if (int rc = validate(d)) return rc;
+  ADVHIP_REQUIRE(x && w_packed && ktab && scale && shift && y, "conv3d+pool211: null pointer");
+  ADVHIP_REQUIRE(d->kt == 1 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->ph == 0 && d->pw == 0,
+                 "conv3d+pool211: 1x1x1 stride-1 convs only (k=%d,%d,%d)", d->kt, d->kh, d->kw);
+  const Geometry g = geometry(d);
+  ADVHIP_REQUIRE(g.K == g.Kpad, "conv3d+pool211: Cin=%d must be a multiple of 32", d->Cin);
+  const int Tp = pool_out(g.To, 2, 2);
+  ADVHIP_REQUIRE(Tp > 0, "conv3d+pool211: T=%d smaller than the temporal window", g.To);
+  const long long y_dense = (long long)d->Cout * Tp * g.Ho * g.Wo;
+  const long long ybs = y_batch_stride > 0 ? y_batch_stride : y_dense;
+  ADVHIP_REQUIRE(ybs >= y_dense && (long long)d->B * ybs < (1ll << 32), "conv3d+pool211: bad y batch stride %lld (one pooled sample: %lld)", ybs, y_dense);
+  ConvArgs a;
+  if (int rc = fill_pool_args(a, d, g, x, x_batch_stride, w_packed, ktab, scale, shift, true)) return rc;
+  a.res = residual; a.y = y; a.y_bstride = (int)ybs; a.Tp = Tp;
+  set_bricks(a, Tp, 1, (a.Wo + 63) / 64);
+  const dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
+  hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, false, 2, EPI_TPOOL>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("conv3d+pool211");
 }

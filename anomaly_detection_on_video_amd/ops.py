@@ -207,6 +207,59 @@ def conv3d_bn_act(x: torch.Tensor, pc: PackedConv, relu: bool = True, residual: 
     return y
 
 
+def conv3d_bn_relu_maxpool233(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """maxpool3d(relu(conv3d(x) * scale + shift), (2,3,3), (2,2,2)) without the un-pooled activation ever reaching HBM
+    (the stem of I3Res50, src/i3d.py:303-306).  Bit-identical to conv3d_bn_act(relu=True) + maxpool3d."""
+    require_gpu(x, out, contiguous=False)
+    if x.dim() != 5 or x.shape[1] != pc.cin:
+        raise ValueError(f"{pc.name}: expected (B,{pc.cin},T,H,W), got {tuple(x.shape)}")
+    B, _, T, H, W = x.shape
+    d = pc.desc(B, T, H, W, True, 0, 1)
+    lib = _lib.load()
+    tp, hp, wp = C.c_int32(), C.c_int32(), C.c_int32()
+    check(lib.advhip_conv3d_pool_out_dims(C.byref(d), 2, 3, 3, 2, 2, 2, C.byref(tp), C.byref(hp), C.byref(wp)), "conv3d_pool_out_dims")
+    shape = (B, pc.cout, tp.value, hp.value, wp.value)
+    if min(shape) <= 0:
+        raise ValueError(f"{pc.name}: input {tuple(x.shape)} too small for conv + (2,3,3) pooling")
+    y = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
+    if tuple(y.shape) != shape or y.dtype != torch.float32 or y.device != x.device:
+        raise ValueError(f"{pc.name}: out {tuple(y.shape)} != {shape}")
+    ktab = ensure_ktab(pc, (T, H, W))
+    need = lib.advhip_conv3d_relu_maxpool233_workspace_bytes(C.byref(d))
+    if need < 0:
+        check(int(need), f"conv3d_relu_maxpool233_workspace_bytes[{pc.name}]")
+    ws = workspace(x.device, need)
+    xbs, ybs = batch_stride(x), batch_stride(y)
+    check(lib.advhip_conv3d_bn_relu_maxpool233_f32(C.byref(d), ptr(x), xbs, ptr(pc.w_packed), ptr(ktab), ptr(pc.scale), ptr(pc.shift),
+                                                   ptr(y), ybs, ptr(ws), need, stream()), f"conv3d+pool233[{pc.name}]")
+    return y
+
+
+def conv3d_bn_act_maxpool211(x: torch.Tensor, pc: PackedConv, relu: bool = True, residual: Optional[torch.Tensor] = None,
+                             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """maxpool3d(act(conv3d(x) * scale + shift (+ residual)), (2,1,1), (2,1,1)) in one launch, for a 1x1x1 stride-1 conv
+    (layer1's last conv3 + maxpool2, src/i3d.py:111-121, 309).  `residual`: un-pooled shape, contiguous."""
+    require_gpu(x, out, contiguous=False)
+    require_gpu(residual)
+    if x.dim() != 5 or x.shape[1] != pc.cin:
+        raise ValueError(f"{pc.name}: expected (B,{pc.cin},T,H,W), got {tuple(x.shape)}")
+    B, _, T, H, W = x.shape
+    if T < 2:
+        raise ValueError(f"{pc.name}: T={T} smaller than the temporal pooling window")
+    shape = (B, pc.cout, T // 2, H, W)
+    y = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
+    if tuple(y.shape) != shape or y.dtype != torch.float32 or y.device != x.device:
+        raise ValueError(f"{pc.name}: out {tuple(y.shape)} != {shape}")
+    if residual is not None and tuple(residual.shape) != (B, pc.cout, T, H, W):
+        raise ValueError(f"{pc.name}: residual {tuple(residual.shape)} != un-pooled output {(B, pc.cout, T, H, W)}")
+    ktab = ensure_ktab(pc, (T, H, W))
+    d = pc.desc(B, T, H, W, relu, 0, 1)
+    check(_lib.load().advhip_conv3d_bn_act_maxpool211_f32(C.byref(d), ptr(x), batch_stride(x), ptr(pc.w_packed), ptr(ktab), ptr(pc.scale),
+                                                          ptr(pc.shift), ptr(residual), ptr(y), batch_stride(y), stream()),
+          f"conv3d+pool211[{pc.name}]")
+    return y
+
+
 def maxpool3d(x: torch.Tensor, kernel, stride, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """`out`: optional destination, contiguous or a channel slice of a wider NCDHW tensor."""
     require_gpu(x)

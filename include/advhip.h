@@ -125,6 +125,32 @@ int advhip_conv3d_bn_act_strided_f32(const advhip_conv3d_desc* d, const float* x
                                      const float* residual, float* y, int64_t y_batch_stride, void* workspace,
                                      int64_t workspace_bytes, void* stream);
 
+/* --- conv + max-pool fused (the two nn.MaxPool3d of I3Res50.forward_single, src/i3d.py:303-309) -------------------
+ * Pooled extents of conv(d) followed by a floor-mode, padding-0 max-pool with window pk* and stride ps*. */
+int advhip_conv3d_pool_out_dims(const advhip_conv3d_desc* d, int32_t pkt, int32_t pkh, int32_t pkw, int32_t pst,
+                                int32_t psh, int32_t psw, int32_t* Tp, int32_t* Hp, int32_t* Wp);
+
+/* y = MaxPool3d(k=(2,3,3), s=(2,2,2), p=0)( relu( conv3d(x, w) * scale + shift ) ): the stem conv1 -> bn1 -> relu ->
+ * maxpool1 of src/i3d.py:303-306 without writing the un-pooled activation (822 MB at B = 32) to HBM.  The conv runs on
+ * m-tiles that are 2(t) x 4(h) x 16(w) bricks of output positions; each brick writes the maxima of the pooling windows
+ * it touches (27 per channel) to `workspace`, and a small second launch maxes the 1, 2 or 4 partials of every pooled
+ * output: the same fp32 conv values as the unfused pair, so the result is bit-identical to advhip_conv3d_bn_act_f32
+ * (relu) + advhip_maxpool3d_f32.  x / y may be channel slices of wider tensors (batch strides in elements, 0 = dense).
+ * d->relu and d->algo / d->splits are ignored (ReLU is part of the op; one tile configuration). */
+int64_t advhip_conv3d_relu_maxpool233_workspace_bytes(const advhip_conv3d_desc* d);
+int advhip_conv3d_bn_relu_maxpool233_f32(const advhip_conv3d_desc* d, const float* x, int64_t x_batch_stride,
+                                         const float* w_packed, const int32_t* ktab, const float* scale, const float* shift,
+                                         float* y, int64_t y_batch_stride, void* workspace, int64_t workspace_bytes,
+                                         void* stream);
+
+/* y = MaxPool3d(k=(2,1,1), s=(2,1,1))( act( conv3d(x, w) * scale + shift (+ residual) ) ) for a 1x1x1 stride-1 conv
+ * (Cin a multiple of 32) in ONE launch: the last Bottleneck of layer1 followed by maxpool2 (src/i3d.py:111-121, 309).
+ * Each m-tile holds both frames of a pooling pair, so the pooling is exact inside the epilogue: the un-pooled
+ * activation is neither written nor read back.  `residual` (nullable) has the UN-pooled conv output's shape, dense. */
+int advhip_conv3d_bn_act_maxpool211_f32(const advhip_conv3d_desc* d, const float* x, int64_t x_batch_stride,
+                                        const float* w_packed, const int32_t* ktab, const float* scale, const float* shift,
+                                        const float* residual, float* y, int64_t y_batch_stride, void* stream);
+
 /* nn.MaxPool3d with zero padding=0, floor mode (src/i3d.py:212-217, 306, 309). */
 int advhip_maxpool3d_f32(const float* x, float* y, int32_t B, int32_t C, int32_t T, int32_t H,
                          int32_t W, int32_t kt, int32_t kh, int32_t kw, int32_t st, int32_t sh,

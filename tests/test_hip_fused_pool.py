@@ -1,0 +1,113 @@
+"""conv + max-pool fused launches (brick-ordered LDS-DMA kernel) vs the unfused pair and the oracle (run with -m gpu).
+
+The fused forms compute exactly the fp32 conv values of advhip_conv3d_bn_act_f32 and pool them inside the launch, so
+the bar is bit-exact against conv3d_bn_act + maxpool3d of this library, and the usual 2e-5 against the CPU oracle's
+max_pool3d(conv_bn_act(...)) (/root/reference/src/i3d.py:303-309)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from anomaly_detection_on_video_amd.weights import synth_tensor
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _pack(name, cin, cout, k, s, p):
+    from anomaly_detection_on_video_amd import ops
+
+    dev = _dev()
+    fan = cin * k[0] * k[1] * k[2]
+    wt = synth_tensor(f"fp.{name}.w", (cout, cin) + tuple(k), scale=float(np.sqrt(6.0 / fan)))
+    g = synth_tensor(f"fp.{name}.g", (cout,), scale=0.5, offset=1.0)
+    be = synth_tensor(f"fp.{name}.b", (cout,), scale=0.25)
+    mu = synth_tensor(f"fp.{name}.m", (cout,), scale=0.25)
+    var = synth_tensor(f"fp.{name}.v", (cout,), scale=0.5, offset=1.0)
+    pc = ops.pack_conv(wt.to(dev), g.to(dev), be.to(dev), mu.to(dev), var.to(dev), 1e-5, s, p, name=name)
+    return pc, (wt, g, be, mu, var)
+
+
+# (B, T, H, W) of the stem input: full size, sizes whose conv output is not a multiple of the brick (4 x 16), odd extents,
+# the smallest input with one pooled output, and one where whole bricks fall outside the tensor
+STEM_SHAPES = [(2, 16, 224, 224), (1, 8, 112, 96), (3, 6, 50, 70), (1, 4, 38, 38), (2, 5, 11, 13), (1, 16, 64, 230)]
+
+
+@pytest.mark.parametrize("shape", STEM_SHAPES, ids=[str(s) for s in STEM_SHAPES])
+def test_stem_conv_relu_maxpool233_is_bit_exact(shape):
+    from anomaly_detection_on_video_amd import ops
+    from oracle import i3d_oracle
+
+    b, t, h, w = shape
+    pc, (wt, g, be, mu, var) = _pack("stem", 3, 64, (5, 7, 7), (2, 2, 2), (2, 3, 3))
+    x = synth_tensor(f"fp.stem.x{shape}", (b, 3, t, h, w), scale=2.0)
+    xd = x.to(_dev())
+    fused = ops.conv3d_bn_relu_maxpool233(xd, pc)
+    for algo in (162, 163, 35):
+        unfused = ops.maxpool3d(ops.conv3d_bn_act(xd, pc, relu=True, algo=algo), (2, 3, 3), (2, 2, 2))
+        assert fused.shape == unfused.shape
+        assert torch.equal(fused, unfused), f"algo {algo}: max diff {float((fused - unfused).abs().max()):.3e}"
+    if b * t * h * w <= 3 * 6 * 50 * 70:
+        ref = torch.nn.functional.max_pool3d(i3d_oracle.conv_bn_act(x, wt, g, be, mu, var, (2, 2, 2), (2, 3, 3), None, True), (2, 3, 3), (2, 2, 2))
+        assert rel_err(fused.cpu(), ref) < 2e-5
+    # into a channel slice of a wider buffer (how layer1.0 consumes it), neighbours untouched
+    wide = torch.full((b, 64 + 64) + tuple(fused.shape[2:]), -7.0, device=_dev())
+    ops.conv3d_bn_relu_maxpool233(xd, pc, out=wide[:, :64])
+    assert torch.equal(wide[:, :64], fused) and (wide[:, 64:] == -7.0).all()
+
+
+def test_conv_relu_maxpool233_other_convs():
+    """Not only the stem: any conv the LDS-DMA kernel runs (here a padded 3x3x3 and an un-padded 1x1x1, Cout 128)."""
+    from anomaly_detection_on_video_amd import ops
+
+    for name, cin, cout, k, s, p, shape in [("c333", 32, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 4, 21, 37)),
+                                            ("c111", 64, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 6, 9, 35))]:
+        pc, _ = _pack(name, cin, cout, k, s, p)
+        x = synth_tensor(f"fp.{name}.x", (shape[0], cin) + shape[1:], scale=2.0).to(_dev())
+        fused = ops.conv3d_bn_relu_maxpool233(x, pc)
+        unfused = ops.maxpool3d(ops.conv3d_bn_act(x, pc, relu=True, algo=162), (2, 3, 3), (2, 2, 2))
+        assert torch.equal(fused, unfused)
+
+
+TPOOL_SHAPES = [(2, 4, 55, 55), (1, 2, 7, 9), (3, 5, 13, 11), (2, 4, 8, 8), (1, 6, 1, 1)]
+
+
+@pytest.mark.parametrize("shape", TPOOL_SHAPES, ids=[str(s) for s in TPOOL_SHAPES])
+@pytest.mark.parametrize("cin,cout", [(64, 256), (128, 64)])
+def test_conv_act_maxpool211_is_bit_exact(shape, cin, cout):
+    from anomaly_detection_on_video_amd import ops
+    from oracle import i3d_oracle
+
+    b, t, h, w = shape
+    pc, (wt, g, be, mu, var) = _pack(f"tp{cin}", cin, cout, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    x = synth_tensor(f"fp.tp.x{shape}{cin}", (b, cin, t, h, w), scale=2.0)
+    res = synth_tensor(f"fp.tp.r{shape}{cout}", (b, cout, t, h, w), scale=1.0)
+    xd, rd = x.to(_dev()), res.to(_dev())
+    for use_res, relu in ((True, True), (False, True), (True, False)):
+        fused = ops.conv3d_bn_act_maxpool211(xd, pc, relu=relu, residual=rd if use_res else None)
+        unfused = ops.maxpool3d(ops.conv3d_bn_act(xd, pc, relu=relu, residual=rd if use_res else None, algo=162), (2, 1, 1), (2, 1, 1))
+        assert fused.shape == unfused.shape == (b, cout, t // 2, h, w)
+        assert torch.equal(fused, unfused), f"res={use_res} relu={relu}: max diff {float((fused - unfused).abs().max()):.3e}"
+        ref = torch.nn.functional.max_pool3d(i3d_oracle.conv_bn_act(x, wt, g, be, mu, var, (1, 1, 1), (0, 0, 0), res if use_res else None, relu), (2, 1, 1), (2, 1, 1))
+        assert rel_err(fused.cpu(), ref) < 2e-5
+    wide_in = torch.full((b, cin + 32, t, h, w), 3.0, device=_dev())
+    wide_in[:, 32:] = xd
+    wide_out = torch.full((b, cout + 8, t // 2, h, w), -5.0, device=_dev())
+    ops.conv3d_bn_act_maxpool211(wide_in[:, 32:], pc, relu=True, residual=rd, out=wide_out[:, 8:])
+    assert torch.equal(wide_out[:, 8:], ops.conv3d_bn_act_maxpool211(xd, pc, relu=True, residual=rd)) and (wide_out[:, :8] == -5.0).all()
+
+
+def test_fused_pool_argument_checks():
+    from anomaly_detection_on_video_amd import _lib, ops
+
+    pc, _ = _pack("chk", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    x = synth_tensor("fp.chk.x", (1, 64, 4, 9, 9)).to(_dev())
+    with pytest.raises(_lib.HipExtensionError, match="1x1x1"):
+        ops.conv3d_bn_act_maxpool211(x, pc)
+    with pytest.raises(ValueError):
+        ops.conv3d_bn_relu_maxpool233(x[:, :, :1, :2, :2].contiguous(), pc)
+    with pytest.raises(ValueError):
+        ops.conv3d_bn_relu_maxpool233(x, pc, out=torch.empty((1, 64, 2, 4, 5), device=_dev()))
