@@ -582,29 +582,16 @@ __device__ __forceinline__ void brick_epilogue(const ConvArgs& a, f32x4 (&acc)[B
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lg = lane >> 4;
   const int c_w = wn * 16 + li;  // this lane's channel row of the pass
+  if constexpr (EPI == EPI_TPOOL) {
 #pragma unroll
-  for (int jn = 0; jn < FN; ++jn) {
-    const int n_w = n0 + 2 * c_w + jn;
-    const float sc = a.scale[n_w], sf = a.shift[n_w];
+    for (int jn = 0; jn < FN; ++jn) {
+      const int n_w = n0 + 2 * c_w + jn;
+      const float sc = a.scale[n_w], sf = a.shift[n_w];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = acc[i][jn][r] * sc + sf;
-      if constexpr (EPI == EPI_POOL233) {
-        // plane position 16*lg + 4*r + i -> (dh, dw) = (pos / BW, pos % BW)
-        const int ot = bk_t * 2 + wm;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int pos = 16 * lg + 4 * r + i;
-          const bool ok = ot < a.To && bk_h * BH + pos / BW < a.Ho && bk_w * BW + pos % BW < a.Wo;
-          v[i] = ok ? fmaxf(v[i], 0.f) : 0.f;
-        }
-      }
-      *reinterpret_cast<float4*>(&smem[c_w * RS + wm * 64 + 16 * lg + 4 * r]) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    __syncthreads();
-    if constexpr (EPI == EPI_TPOOL) {
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<float4*>(&smem[c_w * RS + wm * 64 + 16 * lg + 4 * r]) =
+            make_float4(acc[0][jn][r] * sc + sf, acc[1][jn][r] * sc + sf, acc[2][jn][r] * sc + sf, acc[3][jn][r] * sc + sf);
+      __syncthreads();
       // y[b, n, tp, p] = max_t relu(conv[b, n, 2 tp + t, p] (+ res)): thread = one position p of the brick, 8 channels
       const int pw = tid % BW, c0 = tid / BW;  // BW = 64 positions, 4 channel groups
       const int ow = bk_w * BW + pw;
@@ -623,55 +610,116 @@ __device__ __forceinline__ void brick_epilogue(const ConvArgs& a, f32x4 (&acc)[B
           a.y[(size_t)bk_b * a.y_bstride + ((size_t)n * a.Tp + bk_t) * a.HWo + ow] = fmaxf(v0, v1);
         }
       }
-    } else {
-      // every pooling window (2 t) x (rows 2hp..2hp+2) x (cols 2wp..2wp+2) that meets the brick gets the maximum over the
-      // part of it inside the brick.  Brick rows 4k..4k+3: slot 0 = window hp=2k-1 (row 0 only), slot 1 = hp=2k (rows 0-2,
-      // complete), slot 2 = hp=2k+1 (rows 2-3).  Brick columns 16j..16j+15: slot 0 = wp=8j-1 (column 0), slots 1..7 =
-      // wp=8j..8j+6 (complete), slot 8 = wp=8j+7 (columns 14-15).
-      float* __restrict__ P = a.y + ((size_t)(tile_m * a.tiles_n + tile_n) * FN + jn) * (CH * POOL_SLOTS);
-      for (int o = tid; o < CH * POOL_SLOTS; o += 256) {
-        const int c = o / POOL_SLOTS, s = o - c * POOL_SLOTS;
-        const int rs = s / 9, cs = s - rs * 9;
-        const int h0 = rs == 2 ? 2 : 0, h1 = rs == 0 ? 0 : (rs == 1 ? 2 : 3);
-        const int w0 = cs == 0 ? 0 : 2 * (cs - 1), w1 = cs == 0 ? 0 : (cs == 8 ? 15 : 2 * cs);
-        float m = 0.f;
-        for (int t = 0; t < 2; ++t)
-          for (int h = h0; h <= h1; ++h)
-            for (int w = w0; w <= w1; ++w) m = fmaxf(m, smem[c * RS + t * 64 + h * BW + w]);
-        P[o] = m;
-      }
+      __syncthreads();
     }
-    __syncthreads();
+  } else {
+    // Every pooling window (2 t) x (rows 2hp..2hp+2) x (cols 2wp..2wp+2) that meets the brick gets the maximum over the
+    // part of it inside the brick.  Brick columns 16j..16j+15: column slot 0 = window wp=8j-1 (column 0 only), slots
+    // 1..7 = wp=8j..8j+6 (complete), slot 8 = wp=8j+7 (columns 14-15).  Brick rows 4k..4k+3: row slot 0 = hp=2k-1 (row 0),
+    // slot 1 = hp=2k (rows 0-2, complete), slot 2 = hp=2k+1 (rows 2-3).
+    //   1. a lane holds one whole brick row (16 outputs: w = 4r + i) of one channel and one t plane in registers: BN,
+    //      ReLU and the nine column-slot maxima happen there (15 max instructions);
+    //   2. the 9 values go to LDS as L[channel][t][h][9 (row pitch 12)], channel pitch 100 floats (conflict-free b128 writes);
+    //   3. thread (channel, column slot) maxes over t and the rows of each row slot (8 LDS reads) and stores the three
+    //      row-slot values; the partial tensor is [brick][n-tile][jn][row slot][channel][column slot]: 288 consecutive
+    //      floats per row slot and pass, i.e. coalesced stores.
+    constexpr int LR = 12, LC = 100;
+    const int ot = bk_t * 2 + wm, oh = bk_h * BH + lg;
+    // bricks entirely inside the tensor (all of them at 16 x 224 x 224) skip the per-element range checks
+    const bool inside = bk_t * 2 + 1 < a.To && bk_h * BH + BH - 1 < a.Ho && bk_w * BW + BW - 1 < a.Wo;
+    const int wlim = a.Wo - bk_w * BW;  // columns of the brick inside the tensor
+    const bool row_ok = ot < a.To && oh < a.Ho;
+#pragma unroll
+    for (int jn = 0; jn < FN; ++jn) {
+      const int n_w = n0 + 2 * c_w + jn;
+      const float sc = a.scale[n_w], sf = a.shift[n_w];
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[4 * r + i] = fmaxf(acc[i][jn][r] * sc + sf, 0.f);
+      if (!inside) {  // positions outside the tensor count as 0: neutral for maxima of post-ReLU values
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v[w] = (row_ok && w < wlim) ? v[w] : 0.f;
+      }
+      float pr[8], cs[9];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pr[j] = fmaxf(v[2 * j], v[2 * j + 1]);
+      cs[0] = v[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) cs[k] = fmaxf(pr[k - 1], v[2 * k]);
+      cs[8] = pr[7];
+      float* lrow = smem + c_w * LC + (wm * BH + lg) * LR;
+      *reinterpret_cast<float4*>(lrow) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+      *reinterpret_cast<float4*>(lrow + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
+      lrow[8] = cs[8];
+      __syncthreads();
+      float* __restrict__ P = a.y + ((size_t)(tile_m * a.tiles_n + tile_n) * FN + jn) * (CH * POOL_SLOTS);
+#pragma unroll
+      for (int q0 = 0; q0 < CH * 9; q0 += 256) {
+        const int q = q0 + tid;
+        if (q < CH * 9) {
+          const int c = q / 9, k = q - c * 9;
+          const float* l0 = smem + c * LC + k;
+          float h[4];
+#pragma unroll
+          for (int hh = 0; hh < 4; ++hh) h[hh] = fmaxf(l0[hh * LR], l0[(BH + hh) * LR]);  // max over the two t planes
+          P[q] = h[0];
+          P[CH * 9 + q] = fmaxf(fmaxf(h[0], h[1]), h[2]);
+          P[2 * CH * 9 + q] = fmaxf(h[2], h[3]);
+        }
+      }
+      __syncthreads();
+    }
   }
 }
 
 // Pooled stem output from the per-brick partial maxima: y[b, n, tp, hp, wp] = max over the 1, 2 or 4 bricks the window meets.
-__global__ void stem_pool_merge_kernel(const float* __restrict__ P, float* __restrict__ y, int Cout, int Tp, int Hp, int Wp,
-                                       int nbh, int nbw, int tiles_n, long long total, long long per_sample, long long ypad) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int wp = (int)(i % Wp);
-    long long r = i / Wp;
-    const int hp = (int)(r % Hp);
-    r /= Hp;
-    const int tp = (int)(r % Tp);
-    r /= Tp;
-    const int n = (int)(r % Cout);
-    const int b = (int)(r / Cout);
-    // row contributions (brick, slot): hp even -> complete in brick hp/2; hp odd -> rows 2-3 of brick (hp-1)/2 + row 0 of the next
-    int hb[2], hs[2], nh = 1;
-    if ((hp & 1) == 0) { hb[0] = hp >> 1; hs[0] = 1; }
-    else { hb[0] = hp >> 1; hs[0] = 2; hb[1] = (hp >> 1) + 1; hs[1] = 0; nh = 2; }
-    int wb[2], ws[2], nw = 1;
-    if ((wp & 7) != 7) { wb[0] = wp >> 3; ws[0] = 1 + (wp & 7); }
-    else { wb[0] = wp >> 3; ws[0] = 8; wb[1] = (wp >> 3) + 1; ws[1] = 0; nw = 2; }
-    const int tile_n = n >> 6, nl = n & 63, jn = nl & 1, c = nl >> 1;
-    float m = 0.f;
-    for (int u = 0; u < nh; ++u)
-      for (int v = 0; v < nw; ++v) {
-        const long long tile_m = (((long long)b * Tp + tp) * nbh + hb[u]) * nbw + wb[v];
-        m = fmaxf(m, P[((tile_m * tiles_n + tile_n) * 2 + jn) * (32 * POOL_SLOTS) + c * POOL_SLOTS + hs[u] * 9 + ws[v]]);
-      }
-    y[i + (i / per_sample) * ypad] = m;
+// One workgroup per (sample, n-tile, channel parity jn, tp, hp): it copies the [32 channels][9 column slots] blocks of the
+// row slot(s) that make up pooled row hp from every brick of that brick row into LDS (1152 contiguous bytes each: coalesced),
+// then writes the 32 channels' rows of Wp outputs (coalesced) -- every partial is read exactly once.
+constexpr int MERGE_MAX_NBW = 16;
+__global__ __launch_bounds__(256) void stem_pool_merge_kernel(const float* __restrict__ P, float* __restrict__ y, int Cout, int Tp,
+                                                              int Hp, int Wp, int nbh, int nbw, int tiles_n, FastDiv dWp,
+                                                              long long rows, long long ybs) {
+  extern __shared__ __attribute__((aligned(16))) float L[];  // [2][nbw][288]
+  const long long row = (long long)blockIdx.y * gridDim.x + blockIdx.x;  // ((((b * tiles_n + tile_n) * 2 + jn) * Tp + tp) * Hp + hp
+  if (row >= rows) return;
+  const int hp = (int)(row % Hp);
+  long long r = row / Hp;
+  const int tp = (int)(r % Tp);
+  r /= Tp;
+  const int jn = (int)(r & 1);
+  r >>= 1;
+  const int tile_n = (int)(r % tiles_n), b = (int)(r / tiles_n);
+  const int tid = (int)threadIdx.x;
+  const bool h2 = hp & 1;
+  const int nu = h2 ? 2 : 1;
+  const long long brick_row0 = (((long long)b * Tp + tp) * nbh + (hp >> 1)) * nbw;
+  // 72 float4 per (row-slot, brick) block of 288 contiguous floats
+  for (int e = tid; e < nu * nbw * 72; e += 256) {
+    const int g = e / 72, j = e - g * 72;
+    const int u = g >= nbw ? 1 : 0, wb = g - u * nbw;
+    const int rs = h2 ? (u == 0 ? 2 : 0) : 1;
+    const long long brick = brick_row0 + (long long)u * nbw + wb;
+    *reinterpret_cast<float4*>(L + g * 288 + j * 4) =
+        *reinterpret_cast<const float4*>(P + ((brick * tiles_n + tile_n) * 2 + jn) * (32 * POOL_SLOTS) + rs * 288 + j * 4);
+  }
+  __syncthreads();
+  for (int o = tid; o < 32 * Wp; o += 256) {
+    const int c = (int)dWp.div((unsigned)o), wp = o - c * Wp;
+    const int wb = wp >> 3;
+    const bool w2 = (wp & 7) == 7;
+    const int ws = w2 ? 8 : 1 + (wp & 7);
+    const float* l = L + wb * 288 + c * 9;
+    float m = l[ws];
+    if (w2) m = fmaxf(m, l[288]);
+    if (h2) {
+      m = fmaxf(m, l[nbw * 288 + ws]);
+      if (w2) m = fmaxf(m, l[nbw * 288 + 288]);
+    }
+    const int n = tile_n * 64 + 2 * c + jn;
+    y[(long long)b * ybs + (((long long)n * Tp + tp) * Hp + hp) * Wp + wp] = m;
   }
 }
 
@@ -1722,10 +1770,12 @@ extern "C" int advhip_conv3d_bn_relu_maxpool233_f32(const advhip_conv3d_desc* d,
   if (nocheck) hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, false, 2, EPI_POOL233>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, true, 2, EPI_POOL233>), grid, dim3(256), 0, st, a);
   if (int rc = check_launch("conv3d+pool233")) return rc;
-  const long long total = (long long)d->B * y_dense;
-  const int mgrid = (int)std::min<long long>((total + 255) / 256, 256 * 32);
-  hipLaunchKernelGGL(stem_pool_merge_kernel, dim3(mgrid), dim3(256), 0, st, reinterpret_cast<const float*>(workspace), y, d->Cout,
-                     Tp, Hp, Wp, nbh, nbw, a.tiles_n, total, y_dense, ybs - y_dense);
+  ADVHIP_REQUIRE(nbw <= MERGE_MAX_NBW, "conv3d+pool233: pooled width %d above %d", Wp, MERGE_MAX_NBW * 8 - 1);
+  const long long rows = (long long)d->B * a.tiles_n * 2 * Tp * Hp;
+  ADVHIP_REQUIRE(rows < (1ll << 31), "conv3d+pool233: too many output rows");
+  const unsigned gx = (unsigned)std::min<long long>(rows, 1 << 20), gy = (unsigned)((rows + gx - 1) / gx);
+  hipLaunchKernelGGL(stem_pool_merge_kernel, dim3(gx, gy), dim3(256), (size_t)2 * nbw * 288 * sizeof(float), st, reinterpret_cast<const float*>(workspace), y, d->Cout, Tp,
+                     Hp, Wp, nbh, nbw, a.tiles_n, FastDiv::make((unsigned)Wp), rows, ybs);
   return check_launch("stem_pool_merge");
 }
 

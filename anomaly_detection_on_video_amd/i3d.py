@@ -89,6 +89,9 @@ class I3Res50(nn.Module):
         self._plan_stamp: Optional[Tuple] = None
         # fold a stride-1 downsample branch (layer1.0) into conv3 as one conv over [x ; h] (see prepare)
         self.fuse_downsample = os.environ.get("ADV_I3D_FUSE_DS", "1") == "1"
+        # run conv1+bn1+relu+maxpool1 and layer1's last conv3(+residual+relu)+maxpool2 as conv launches that pool in
+        # their epilogue (src/i3d.py:303-309): the un-pooled activations (822 + 396 MB at B=32) never reach HBM
+        self.fuse_pool = os.environ.get("ADV_I3D_FUSE_POOL", "1") == "1"
         # a forward is spread over this many HIP streams, each taking a contiguous part of the batch (see _run_streams)
         self.streams = int(os.environ.get("ADV_I3D_STREAMS", "2"))
         self._side_streams: List[torch.cuda.Stream] = []
@@ -177,6 +180,16 @@ class I3Res50(nn.Module):
             if lname == "layer1":
                 plan.append(_Unit("maxpool", kernel=(2, 1, 1), stride=(2, 1, 1)))
         plan.append(_Unit("avgpool"))
+        # pooling fused into the producing conv: the maxpool unit stays in the plan (shape bookkeeping, the un-fused
+        # form used for per-stage taps) and is skipped when its producer has pooled already
+        for prev, u in zip(plan, plan[1:]):
+            if u.kind != "maxpool":
+                continue
+            if prev.kind == "stem" and (u.kernel, u.stride) == ((2, 3, 3), (2, 2, 2)):
+                prev.pool_unit, u.absorbed = u, True
+            elif (prev.kind == "bottleneck" and not prev.cat and (u.kernel, u.stride) == ((2, 1, 1), (2, 1, 1))
+                  and prev.convs[2].kernel == (1, 1, 1) and prev.convs[2].stride == (1, 1, 1) and prev.convs[2].cin % 32 == 0):
+                prev.pool_unit, u.absorbed = u, True
         self._plan, self._plan_stamp = plan, stamp
 
     def packed_convs(self) -> List[ops.PackedConv]:
@@ -217,14 +230,17 @@ class I3Res50(nn.Module):
             if events is not None:
                 mark()
             n = self._n_streams(x.shape[0]) if taps is None else 1
+            fused = self.fuse_pool and taps is None  # taps want every stage's own output: the un-fused launches
             if n > 1:
                 x = self._run_streams(x, n)
             else:
                 for u in self._plan:
+                    if fused and u.absorbed:
+                        continue
                     pool = events is not None and u.kind in ("maxpool", "avgpool")
                     if pool:
                         mark()
-                    x = u.run(x)
+                    x = u.run(x, fused)
                     if pool:
                         mark()
                     if taps is not None and u.name:
@@ -274,7 +290,8 @@ class I3Res50(nn.Module):
 
         def chain(part: torch.Tensor) -> torch.Tensor:
             for u in self._plan:
-                part = u.run(part)
+                if not (self.fuse_pool and u.absorbed):
+                    part = u.run(part, self.fuse_pool)
             return part
 
         parts = [chain(x[bounds[0]:bounds[1]])]
@@ -303,9 +320,20 @@ class _Unit:
         self.kernel, self.stride = kernel, stride
         self.cat = cat            # bottleneck: > 0 = input is the [x ; h] buffer, x = its first `cat` channels
         self.cat_channels = 0     # maxpool: > 0 = allocate that many extra channels behind the pooled ones
+        self.pool_unit: Optional["_Unit"] = None  # stem / bottleneck: the maxpool unit that follows and can be fused into this one
+        self.absorbed = False     # maxpool: its producer can pool in its own epilogue
 
-    def run(self, x: torch.Tensor) -> torch.Tensor:
+    def run(self, x: torch.Tensor, fused: bool = False) -> torch.Tensor:
+        fused = fused and self.pool_unit is not None
         if self.kind == "stem":
+            if fused:  # conv1 + bn1 + relu + maxpool1 (src/i3d.py:303-306), straight into the [x ; h] buffer of layer1.0
+                pu = self.pool_unit
+                if pu.cat_channels:
+                    d = ops.conv_pool_out_dims(tuple(x.shape[2:]), self.convs[0], pu.kernel, pu.stride)
+                    wide = torch.empty((x.shape[0], self.convs[0].cout + pu.cat_channels) + d, device=x.device, dtype=torch.float32)
+                    ops.conv3d_bn_relu_maxpool233(x, self.convs[0], out=wide[:, : self.convs[0].cout])
+                    return wide
+                return ops.conv3d_bn_relu_maxpool233(x, self.convs[0])
             return ops.conv3d_bn_act(x, self.convs[0], relu=True)
         if self.kind == "maxpool":
             if self.cat_channels:
@@ -324,6 +352,8 @@ class _Unit:
         h = ops.conv3d_bn_act(x, c1, relu=True)
         h = ops.conv3d_bn_act(h, c2, relu=True)
         res = ops.conv3d_bn_act(x, ds, relu=False) if ds is not None else x
+        if fused:  # conv3 + bn3 + residual + relu + maxpool2 (src/i3d.py:111-121, 309) in one launch
+            return ops.conv3d_bn_act_maxpool211(h, c3, relu=True, residual=res)
         return ops.conv3d_bn_act(h, c3, relu=True, residual=res)
 
 

@@ -207,6 +207,11 @@ def conv3d_bn_act(x: torch.Tensor, pc: PackedConv, relu: bool = True, residual: 
     return y
 
 
+def conv_pool_out_dims(in_thw: Sequence[int], pc: "PackedConv", pool_kernel, pool_stride) -> Tuple[int, int, int]:
+    """(T, H, W) of conv `pc` on in_thw followed by a floor-mode, padding-0 max-pool."""
+    return conv_out_dims(conv_out_dims(in_thw, pc.kernel, pc.stride, pc.padding), _triple(pool_kernel), _triple(pool_stride), (0, 0, 0))
+
+
 def conv3d_bn_relu_maxpool233(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """maxpool3d(relu(conv3d(x) * scale + shift), (2,3,3), (2,2,2)) without the un-pooled activation ever reaching HBM
     (the stem of I3Res50, src/i3d.py:303-306).  Bit-identical to conv3d_bn_act(relu=True) + maxpool3d."""

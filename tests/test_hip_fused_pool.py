@@ -111,3 +111,28 @@ def test_fused_pool_argument_checks():
         ops.conv3d_bn_relu_maxpool233(x[:, :, :1, :2, :2].contiguous(), pc)
     with pytest.raises(ValueError):
         ops.conv3d_bn_relu_maxpool233(x, pc, out=torch.empty((1, 64, 2, 4, 5), device=_dev()))
+
+
+def test_fullnet_fused_pools_equal_unfused_plan():
+    """I3Res50 with conv1+maxpool1 and layer1.2.conv3+maxpool2 fused (the default) vs the same plan with the pools as
+    their own launches: identical bits (the fused launches pool the very same fp32 conv values), on the direct forward
+    and per stream part; per-stage taps still come from the un-fused launches."""
+    from anomaly_detection_on_video_amd.i3d import I3Res50
+    from anomaly_detection_on_video_amd.weights import synth_i3d_state_dict, synth_input
+
+    m = I3Res50(use_nl=False)
+    m.load_state_dict(synth_i3d_state_dict(), strict=True)
+    m = m.eval().to(_dev())
+    assert m.fuse_pool
+    for shape, seed in (((2, 3, 16, 224, 224), 0), ((3, 3, 8, 112, 96), 7), ((16, 3, 16, 64, 80), 2)):
+        x = synth_input(shape, seed).to(_dev())
+        m.fuse_pool = True
+        y_f = m(x)
+        m.fuse_pool = False
+        y_u = m(x)
+        m.fuse_pool = True
+        assert torch.equal(y_f, y_u), f"{shape}: max diff {float((y_f - y_u).abs().max()):.3e}"
+    assert sum(1 for u in m._plan if u.absorbed) == 2
+    taps = {}
+    m.forward_single(synth_input((1, 3, 16, 224, 224), 1).to(_dev()), taps)
+    assert tuple(taps["stem"].shape) == (1, 64, 8, 112, 112) and tuple(taps["layer1.2"].shape) == (1, 256, 4, 55, 55)
