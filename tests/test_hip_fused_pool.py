@@ -115,8 +115,8 @@ def test_fused_pool_argument_checks():
 
 def test_fullnet_fused_pools_equal_unfused_plan():
     """I3Res50 with conv1+maxpool1 and layer1.2.conv3+maxpool2 fused (the default) vs the same plan with the pools as
-    their own launches: identical bits (the fused launches pool the very same fp32 conv values), on the direct forward
-    and per stream part; per-stage taps still come from the un-fused launches."""
+    their own launches: identical bits at full size (the fused launches pool the very same fp32 conv values), on the
+    direct forward and per stream part; per-stage taps still come from the un-fused launches."""
     from anomaly_detection_on_video_amd.i3d import I3Res50
     from anomaly_detection_on_video_amd.weights import synth_i3d_state_dict, synth_input
 
@@ -131,7 +131,8 @@ def test_fullnet_fused_pools_equal_unfused_plan():
         m.fuse_pool = False
         y_u = m(x)
         m.fuse_pool = True
-        assert torch.equal(y_f, y_u), f"{shape}: max diff {float((y_f - y_u).abs().max()):.3e}"
+        # small inputs: the un-fused convs may run split-K (another fp32 summation order); otherwise the same bits
+        assert torch.equal(y_f, y_u) if shape[-1] == 224 else rel_err(y_f.cpu(), y_u.cpu()) < 1e-5, f"{shape}: max diff {float((y_f - y_u).abs().max()):.3e}"
     assert sum(1 for u in m._plan if u.absorbed) == 2
     taps = {}
     m.forward_single(synth_input((1, 3, 16, 224, 224), 1).to(_dev()), taps)
