@@ -68,6 +68,14 @@ _P = C.c_void_p
 _I = C.c_int32
 _L = C.c_int64
 
+
+class GemmDesc(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("M", "N", "K", "batch")]
+                + [(n, C.c_int64) for n in ("sAb", "sAm", "sAk", "sBb", "sBk", "sBn", "sCb", "sCm", "sCn")]
+                + [("alpha", C.c_float), ("beta", C.c_float), ("act", C.c_int32)]
+                + [(n, C.c_void_p) for n in ("bias_m", "bias_n", "ln_u", "ln_mu", "ln_rs", "residual")])
+
+
 # name -> (restype, argtypes); every symbol include/advhip.h declares
 SIGNATURES = {
     "advhip_abi_version": (C.c_int, []),
@@ -86,6 +94,8 @@ SIGNATURES = {
     "advhip_conv3d_relu_maxpool233_workspace_bytes": (_L, [C.POINTER(ConvDesc)]),
     "advhip_conv3d_bn_relu_maxpool233_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P]),
     "advhip_conv3d_bn_act_maxpool211_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _L, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "advhip_bgemm_f32": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P]),
+    "advhip_softmax_rows_f32": (C.c_int, [_P, _P, _L, _I, C.c_float, _P]),
     "advhip_maxpool3d_f32": (C.c_int, [_P, _P] + [_I] * 11 + [_P]),
     "advhip_maxpool3d_strided_f32": (C.c_int, [_P, _P, _L] + [_I] * 11 + [_P]),
     "advhip_global_avgpool_f32": (C.c_int, [_P, _P, _L, _I, _P]),

@@ -39,11 +39,6 @@ class Bottleneck(nn.Module):
 
     def __init__(self, inplanes, planes, stride, downsample, temp_conv, temp_stride, use_nl=False):
         super().__init__()
-        if use_nl:
-            raise NotImplementedError(
-                "NonLocalBlock is dead code under the reference's only call site (use_nl=False, "
-                "src/i3d.py:219,338) and is not part of the HIP path"
-            )
         self.conv1 = nn.Conv3d(inplanes, planes, kernel_size=(1 + temp_conv * 2, 1, 1), stride=(temp_stride, 1, 1),
                                padding=(temp_conv, 0, 0), bias=False)
         self.bn1 = nn.BatchNorm3d(planes)
@@ -54,10 +49,79 @@ class Bottleneck(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
         self.stride = stride
-        self.nl = None
+        outplanes = planes * 4
+        self.nl = NonLocalBlock(outplanes, outplanes, outplanes // 2) if use_nl else None
 
     def forward(self, x):  # pragma: no cover - guarded
         raise _lib.HipExtensionError("Bottleneck runs only inside I3Res50's fused HIP plan; call the parent model")
+
+
+class NonLocalBlock(nn.Module):
+    """Embedded-Gaussian non-local block (src/i3d.py:124-195): same children / state-dict keys as the reference
+    (theta, phi, g, out: 1x1x1 Conv3d WITH bias; bn; maxpool (1,2,2)).  Dead code under the reference's factory
+    (use_nl=False, src/i3d.py:338) but part of I3Res50(use_nl=True).  Runs as HIP launches only:
+
+        mp = maxpool(x)                                   advhip_maxpool3d_f32
+        theta = theta(x); [phi ; g] = [phi ; g](mp)       two conv launches (phi and g share one: Cout = 2*inner)
+        p = softmax(theta^T.phi * inner**-0.5)            advhip_bgemm_f32 (alpha in the epilogue) + advhip_softmax_rows_f32
+        t = g.p^T                                         advhip_bgemm_f32
+        y = bn(out(t)) + x                                conv launch, BN folded, residual in the epilogue (no ReLU)
+    """
+
+    def __init__(self, dim_in, dim_out, dim_inner):
+        super().__init__()
+        self.dim_in, self.dim_inner, self.dim_out = dim_in, dim_inner, dim_out
+        self.theta = nn.Conv3d(dim_in, dim_inner, kernel_size=(1, 1, 1), stride=(1, 1, 1), padding=(0, 0, 0))
+        self.maxpool = nn.MaxPool3d(kernel_size=(1, 2, 2), stride=(1, 2, 2), padding=(0, 0, 0))
+        self.phi = nn.Conv3d(dim_in, dim_inner, kernel_size=(1, 1, 1), stride=(1, 1, 1), padding=(0, 0, 0))
+        self.g = nn.Conv3d(dim_in, dim_inner, kernel_size=(1, 1, 1), stride=(1, 1, 1), padding=(0, 0, 0))
+        self.out = nn.Conv3d(dim_inner, dim_out, kernel_size=(1, 1, 1), stride=(1, 1, 1), padding=(0, 0, 0))
+        self.bn = nn.BatchNorm3d(dim_out)
+        self._packed = None
+        self._stamp = None
+
+    def prepare(self, name: str = "nl"):
+        stamp = tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        if self._packed is not None and stamp == self._stamp:
+            return self._packed
+        if self.theta.weight.device.type != "cuda":
+            raise _lib.HipExtensionError("NonLocalBlock runs only as HIP kernels on an AMD GPU (call .cuda()); there is no CPU fallback")
+
+        def biased(w, b, nm):  # conv with bias, no BN: scale 1, shift = bias
+            one, zero = torch.ones_like(b), torch.zeros_like(b)
+            return ops.pack_conv(w.detach(), one, b.detach(), zero, one, 0.0, (1, 1, 1), (0, 0, 0), name=f"{name}.{nm}")
+
+        theta = biased(self.theta.weight, self.theta.bias, "theta")
+        phig = biased(torch.cat([self.phi.weight.detach(), self.g.weight.detach()], dim=0).contiguous(),
+                      torch.cat([self.phi.bias.detach(), self.g.bias.detach()]), "phi+g")
+        # bn(out(t) + b) = bn'(out(t)) with running_mean' = running_mean - b
+        out = ops.pack_conv(self.out.weight.detach(), self.bn.weight.detach(), self.bn.bias.detach(),
+                            self.bn.running_mean.detach() - self.out.bias.detach(), self.bn.running_var.detach(), self.bn.eps,
+                            (1, 1, 1), (0, 0, 0), name=f"{name}.out")
+        self._packed, self._stamp = (theta, phig, out), stamp
+        return self._packed
+
+    def run(self, x: torch.Tensor, name: str = "nl") -> torch.Tensor:
+        if self.training:
+            raise _lib.HipExtensionError("NonLocalBlock HIP path implements eval-mode BatchNorm only; call .eval()")
+        theta_pc, phig_pc, out_pc = self.prepare(name)
+        B, _, T, H, W = x.shape
+        inner = self.dim_inner
+        if H < 2 or W < 2:
+            raise ValueError(f"NonLocalBlock: input {tuple(x.shape)} smaller than the (1,2,2) pooling window")
+        mp = ops.maxpool3d(x, (1, 2, 2), (1, 2, 2))
+        theta = ops.conv3d_bn_act(x, theta_pc, relu=False).view(B, inner, -1)               # (B, inner, N)
+        pg = ops.conv3d_bn_act(mp, phig_pc, relu=False).view(B, 2 * inner, -1)              # (B, 2*inner, Np)
+        att = ops.bgemm(theta.transpose(1, 2), pg[:, :inner], alpha=float(inner) ** -0.5)   # (B, N, Np)
+        ops.softmax_rows(att, out=att)
+        t = ops.bgemm(pg[:, inner:], att.transpose(1, 2))                                   # (B, inner, N)
+        return ops.conv3d_bn_act(t.view(B, inner, T, H, W), out_pc, relu=False, residual=x)
+
+    def forward(self, x):
+        with torch.no_grad():
+            if not x.is_cuda:
+                raise _lib.HipExtensionError("input is not on the GPU; there is no CPU fallback")
+            return self.run(x.detach().contiguous())
 
 
 class I3Res50(nn.Module):
@@ -66,16 +130,15 @@ class I3Res50(nn.Module):
     def __init__(self, block=Bottleneck, layers=[3, 4, 6, 3], use_nl=False):
         self.inplanes = 64
         super().__init__()
-        if use_nl:
-            raise NotImplementedError("non-local blocks are outside the hot path (src/i3d.py:219)")
+        nonlocal_mod = 2 if use_nl else 1000  # src/i3d.py:219
         self.conv1 = nn.Conv3d(3, 64, kernel_size=(5, 7, 7), stride=(2, 2, 2), padding=(2, 3, 3), bias=False)
         self.bn1 = nn.BatchNorm3d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool1 = nn.MaxPool3d(kernel_size=(2, 3, 3), stride=(2, 2, 2), padding=(0, 0, 0))
         self.maxpool2 = nn.MaxPool3d(kernel_size=(2, 1, 1), stride=(2, 1, 1), padding=(0, 0, 0))
         self.layer1 = self._make_layer(block, 64, layers[0], 1, [1, 1, 1], [1, 1, 1])
-        self.layer2 = self._make_layer(block, 128, layers[1], 2, [1, 0, 1, 0], [1, 1, 1, 1])
-        self.layer3 = self._make_layer(block, 256, layers[2], 2, [1, 0, 1, 0, 1, 0], [1, 1, 1, 1, 1, 1])
+        self.layer2 = self._make_layer(block, 128, layers[1], 2, [1, 0, 1, 0], [1, 1, 1, 1], nonlocal_mod)
+        self.layer3 = self._make_layer(block, 256, layers[2], 2, [1, 0, 1, 0, 1, 0], [1, 1, 1, 1, 1, 1], nonlocal_mod)
         self.layer4 = self._make_layer(block, 512, layers[3], 2, [0, 1, 0], [1, 1, 1])
         self.avgpool = nn.AdaptiveAvgPool3d((1, 1, 1))
         # same initialisation as the reference (src/i3d.py:246-251)
@@ -98,7 +161,7 @@ class I3Res50(nn.Module):
         # layer name -> ADVHIP_ALGO_* override (tuning hook)
         self.algo_overrides: Dict[str, int] = {}
 
-    def _make_layer(self, block, planes, blocks, stride, temp_conv, temp_stride):
+    def _make_layer(self, block, planes, blocks, stride, temp_conv, temp_stride, nonlocal_mod=1000):
         downsample = None
         if stride != 1 or self.inplanes != planes * block.expansion or temp_stride[0] != 1:
             downsample = nn.Sequential(
@@ -109,7 +172,7 @@ class I3Res50(nn.Module):
         layers = [block(self.inplanes, planes, stride, downsample, temp_conv[0], temp_stride[0], False)]
         self.inplanes = planes * block.expansion
         for i in range(1, blocks):
-            layers.append(block(self.inplanes, planes, 1, None, temp_conv[i], temp_stride[i], False))
+            layers.append(block(self.inplanes, planes, 1, None, temp_conv[i], temp_stride[i], i % nonlocal_mod == nonlocal_mod - 1))
         return nn.Sequential(*layers)
 
     # ------------------------------------------------------------------ plan (load-time packing)
@@ -175,8 +238,11 @@ class I3Res50(nn.Module):
                     self._pack(blk.conv1, blk.bn1, f"{p}.conv1"),
                     self._pack(blk.conv2, blk.bn2, f"{p}.conv2"),
                     self._pack(blk.conv3, blk.bn3, f"{p}.conv3"),
-                    ds, name=p,
+                    ds, name=p if blk.nl is None else "",
                 ))
+                if blk.nl is not None:  # Bottleneck.forward applies the non-local block last (src/i3d.py:118-119)
+                    blk.nl.prepare(f"{p}.nl")
+                    plan.append(_Unit("nonlocal", name=p, nl=blk.nl))
             if lname == "layer1":
                 plan.append(_Unit("maxpool", kernel=(2, 1, 1), stride=(2, 1, 1)))
         plan.append(_Unit("avgpool"))
@@ -260,6 +326,11 @@ class I3Res50(nn.Module):
         for u in self._plan:
             if u.kind == "maxpool":
                 dims = ops.conv_out_dims(dims, u.kernel, u.stride, (0, 0, 0))
+            elif u.kind == "nonlocal":
+                theta_pc, phig_pc, out_pc = u.nl.prepare(u.name + ".nl")
+                ops.ensure_ktab(theta_pc, dims, batch)
+                ops.ensure_ktab(phig_pc, ops.conv_out_dims(dims, (1, 2, 2), (1, 2, 2), (0, 0, 0)), batch)
+                ops.ensure_ktab(out_pc, dims, batch)
             elif u.kind in ("stem", "bottleneck"):
                 if u.kind == "bottleneck" and u.convs[3] is not None:
                     ops.ensure_ktab(u.convs[3], dims, batch)  # the downsample branch reads the unit's input
@@ -313,10 +384,11 @@ class I3Res50(nn.Module):
 class _Unit:
     """One step of the flat execution plan."""
 
-    def __init__(self, kind, *convs, name: str = "", kernel=None, stride=None, cat: int = 0):
+    def __init__(self, kind, *convs, name: str = "", kernel=None, stride=None, cat: int = 0, nl=None):
         self.kind = kind
         self.convs = convs
-        self.name = name or kind
+        self.name = name or (kind if kind != "bottleneck" else "")
+        self.nl = nl
         self.kernel, self.stride = kernel, stride
         self.cat = cat            # bottleneck: > 0 = input is the [x ; h] buffer, x = its first `cat` channels
         self.cat_channels = 0     # maxpool: > 0 = allocate that many extra channels behind the pooled ones
@@ -344,6 +416,8 @@ class _Unit:
             return ops.maxpool3d(x, self.kernel, self.stride)
         if self.kind == "avgpool":
             return ops.global_avgpool(x)
+        if self.kind == "nonlocal":
+            return self.nl.run(x, self.name + ".nl")
         c1, c2, c3, ds = self.convs
         if self.cat:  # x is the wide buffer [x ; room for h]: conv2 writes h into its second half, c3 is the fused conv
             h = ops.conv3d_bn_act(x[:, : self.cat], c1, relu=True)

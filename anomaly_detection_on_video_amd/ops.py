@@ -289,3 +289,62 @@ def global_avgpool(x: torch.Tensor) -> torch.Tensor:
     y = torch.empty((B, Cc, 1, 1, 1), device=x.device, dtype=torch.float32)
     check(_lib.load().advhip_global_avgpool_f32(ptr(x), ptr(y), B * Cc, n, stream()), "global_avgpool")
     return y
+
+
+def bgemm(a: torch.Tensor, b: torch.Tensor, *, alpha: float = 1.0, bias_m: Optional[torch.Tensor] = None,
+          bias_n: Optional[torch.Tensor] = None, act: int = 0, residual: Optional[torch.Tensor] = None, beta: float = 1.0,
+          ln: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[i] = epi(alpha * a[i] @ b[i]) on the fp32 MFMA (include/advhip.h: advhip_bgemm_f32).  a: (batch, M, K), b: (batch, K, N)
+    -- any views whose last two dims have one unit stride each (transposes and channel slices included; batch stride 0 =
+    broadcast); 2-D operands are one batch.  `ln` = (u[M], mu[batch*N], rs[batch*N]): the LayerNorm fold of the header.
+    `act`: 0 none, 1 ReLU, 2 GELU(erf).  `residual`: like out."""
+    if a.dim() == 2:
+        a = a.unsqueeze(0)
+    if b.dim() == 2:
+        b = b.unsqueeze(0)
+    require_gpu(a, b, out, residual, contiguous=False)
+    require_gpu(bias_m, bias_n)
+    batch = max(a.shape[0], b.shape[0])
+    if a.dim() != 3 or b.dim() != 3 or a.shape[2] != b.shape[1] or a.shape[0] not in (1, batch) or b.shape[0] not in (1, batch):
+        raise ValueError(f"bgemm: incompatible operands {tuple(a.shape)} x {tuple(b.shape)}")
+    if a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise _lib.HipExtensionError("bgemm computes in fp32")
+    M, K, N = a.shape[1], a.shape[2], b.shape[2]
+    y = out if out is not None else torch.empty((batch, M, N), device=a.device, dtype=torch.float32)
+    if y.dim() == 2:
+        y = y.unsqueeze(0)
+    if tuple(y.shape) != (batch, M, N) or y.dtype != torch.float32:
+        raise ValueError(f"bgemm: out {tuple(y.shape)} != {(batch, M, N)}")
+    if residual is not None:
+        if residual.dim() == 2:
+            residual = residual.unsqueeze(0)
+        if tuple(residual.shape) != (batch, M, N) or residual.stride() != y.stride():
+            raise ValueError("bgemm: residual must have out's shape and strides")
+
+    def strides(t, nb):
+        sb = t.stride(0) if t.shape[0] == nb and nb > 1 else 0
+        return sb, t.stride(1), t.stride(2)
+
+    sa, sb_, sc = strides(a, batch), strides(b, batch), strides(y, batch)
+    if M > 1 and K > 1 and 1 not in sa[1:] or N > 1 and K > 1 and 1 not in sb_[1:]:
+        raise ValueError(f"bgemm: each operand needs a unit stride in its last two dims (got {a.stride()}, {b.stride()})")
+    # a size-1 dim's stride is arbitrary: give the kernel a consistent unit stride
+    sa = (sa[0], 1 if M == 1 and sa[2] != 1 else sa[1], 1 if K == 1 and sa[1] != 1 else sa[2])
+    sb_ = (sb_[0], 1 if K == 1 and sb_[2] != 1 else sb_[1], 1 if N == 1 and sb_[1] != 1 else sb_[2])
+    d = _lib.GemmDesc(M, N, K, batch, *sa, *sb_, *sc, float(alpha), float(beta), int(act), ptr(bias_m), ptr(bias_n),
+                      ptr(ln[0]) if ln else None, ptr(ln[1]) if ln else None, ptr(ln[2]) if ln else None, ptr(residual))
+    if ln is not None:
+        require_gpu(*ln)
+        if ln[0].numel() != M or ln[1].numel() != batch * N or ln[2].numel() != batch * N:
+            raise ValueError("bgemm: LayerNorm fold vectors must be u[M], mu[batch*N], rs[batch*N]")
+    check(_lib.load().advhip_bgemm_f32(C.byref(d), ptr(a), ptr(b), ptr(y), stream()), "bgemm")
+    return y if out is None or out.dim() == 3 else out
+
+
+def softmax_rows(x: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(x * scale) over the last (contiguous) dim, one wavefront per row; out may be x."""
+    require_gpu(x, out)
+    y = out if out is not None else torch.empty_like(x)
+    n = x.shape[-1]
+    check(_lib.load().advhip_softmax_rows_f32(ptr(x), ptr(y), x.numel() // n, n, C.c_float(scale), stream()), "softmax_rows")
+    return y

@@ -55,7 +55,13 @@ def synth_input(shape: Tuple[int, ...], seed: int = 0, name: str = "input") -> t
 
 
 # --------------------------------------------------------------------------- I3D
-def i3d_state_dict_spec() -> Iterable[Tuple[str, Tuple[int, ...], str]]:
+def nonlocal_positions(use_nl: bool):
+    """Blocks that carry a NonLocalBlock when I3Res50(use_nl=True): nonlocal_mod = 2 on layer2 and layer3, i.e. every
+    odd block index there (src/i3d.py:219, 221-240, 296)."""
+    return {("layer2", 1), ("layer2", 3), ("layer3", 1), ("layer3", 3), ("layer3", 5)} if use_nl else set()
+
+
+def i3d_state_dict_spec(use_nl: bool = False) -> Iterable[Tuple[str, Tuple[int, ...], str]]:
     """(key, shape, kind) for every entry of the reference I3Res50 state dict.
 
     Topology restated from `src/i3d.py:198-300` (layers [3,4,6,3]; temporal kernels
@@ -90,21 +96,29 @@ def i3d_state_dict_spec() -> Iterable[Tuple[str, Tuple[int, ...], str]]:
             if i == 0:
                 yield f"{p}.downsample.0.weight", (planes * 4, inplanes, 1, 1, 1), "conv"
                 yield from bn(f"{p}.downsample.1", planes * 4)
+            if (lname, i) in nonlocal_positions(use_nl):  # NonLocalBlock(outplanes, outplanes, outplanes // 2), src/i3d.py:93-96
+                outp, inner = planes * 4, planes * 2
+                for conv, (co, ci) in (("theta", (inner, outp)), ("phi", (inner, outp)), ("g", (inner, outp)), ("out", (outp, inner))):
+                    yield f"{p}.nl.{conv}.weight", (co, ci, 1, 1, 1), "conv"
+                    yield f"{p}.nl.{conv}.bias", (co,), "conv_bias"
+                yield from bn(f"{p}.nl.bn", outp)
             inplanes = planes * 4
 
 
-def synth_i3d_state_dict(salt: int = 0) -> Dict[str, torch.Tensor]:
+def synth_i3d_state_dict(salt: int = 0, use_nl: bool = False) -> Dict[str, torch.Tensor]:
     sd: Dict[str, torch.Tensor] = {}
-    for key, shape, kind in i3d_state_dict_spec():
+    for key, shape, kind in i3d_state_dict_spec(use_nl):
         if kind == "conv":
             fan_in = int(np.prod(shape[1:]))
             # uniform[-a,a] has variance a^2/3; aim at var = 2/fan_in (ReLU-preserving)
             a = float(np.sqrt(3.0 * 2.0 / fan_in))
             sd[key] = synth_tensor(key, shape, scale=a, salt=salt)
+        elif kind == "conv_bias":
+            sd[key] = synth_tensor(key, shape, scale=0.1, salt=salt)
         elif kind == "bn_gamma":
             # the last BN of every residual branch gets a smaller gain so that 16 stacked
             # residual additions do not blow the activations up
-            small = key.endswith("bn3.weight") or ".downsample.1." in key
+            small = key.endswith("bn3.weight") or ".downsample.1." in key or ".nl.bn." in key
             centre = 0.5 if small else 1.0
             sd[key] = synth_tensor(key, shape, scale=0.5 * centre, offset=centre, salt=salt)
         elif kind == "bn_beta":
@@ -118,6 +132,27 @@ def synth_i3d_state_dict(salt: int = 0) -> Dict[str, torch.Tensor]:
         else:  # pragma: no cover
             raise AssertionError(kind)
     return sd
+
+
+NONLOCAL_CASES = ["nl512", "nl1024", "nl512odd"]
+
+
+def synth_nonlocal_case(name: str):
+    """(dim, inner, state dict, x) of a stand-alone NonLocalBlock(dim, dim, inner) parity case (src/i3d.py:124-195): the
+    two block sizes of I3Res50(use_nl=True) on small clips, one with odd spatial extents (the (1,2,2) pool floors)."""
+    dim, inner, (b, t, h, w) = {"nl512": (512, 256, (2, 2, 6, 8)), "nl1024": (1024, 512, (1, 2, 4, 6)),
+                                "nl512odd": (512, 256, (1, 3, 7, 5))}[name]
+    sd: Dict[str, torch.Tensor] = {}
+    for conv, (co, ci) in (("theta", (inner, dim)), ("phi", (inner, dim)), ("g", (inner, dim)), ("out", (dim, inner))):
+        sd[f"{conv}.weight"] = synth_tensor(f"{name}.{conv}.w", (co, ci, 1, 1, 1), scale=float(np.sqrt(3.0 / ci)))
+        sd[f"{conv}.bias"] = synth_tensor(f"{name}.{conv}.b", (co,), scale=0.1)
+    sd["bn.weight"] = synth_tensor(f"{name}.bn.g", (dim,), scale=0.25, offset=0.5)
+    sd["bn.bias"] = synth_tensor(f"{name}.bn.b", (dim,), scale=0.25)
+    sd["bn.running_mean"] = synth_tensor(f"{name}.bn.m", (dim,), scale=0.25)
+    sd["bn.running_var"] = synth_tensor(f"{name}.bn.v", (dim,), scale=0.5, offset=1.0)
+    sd["bn.num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+    x = synth_tensor(f"{name}.x", (b, dim, t, h, w), scale=2.0)
+    return dim, inner, sd, x
 
 
 # --------------------------------------------------------------------------- generic

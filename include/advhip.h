@@ -163,6 +163,34 @@ int advhip_maxpool3d_strided_f32(const float* x, float* y, int64_t y_batch_strid
 /* nn.AdaptiveAvgPool3d((1,1,1)) (src/i3d.py:244, 314): x (rows, n) -> y (rows), mean over n. */
 int advhip_global_avgpool_f32(const float* x, float* y, int64_t rows, int32_t n, void* stream);
 
+/* --- batched strided GEMM (fp32 MFMA) ---------------------------------------------------------------------------------
+ * C[b,m,n] = epi( alpha * sum_k A[b,m,k] * B[b,k,n] ), element (b,m,k) of A at A + b*sAb + m*sAm + k*sAk (strides in
+ * elements; one of sAm / sAk and one of sBk / sBn must be 1), likewise B and C.  Replaces the torch.bmm pair of
+ * NonLocalBlock.forward (src/i3d.py:171-178) and the Conv1d / Linear / einsum contractions of the MGFN scorer and their
+ * backward products (src/models/mgfn/modeling_mgfn.py:49-64, 96-123, 150-205).  Epilogue, in this order (every pointer
+ * nullable): LayerNorm fold  v = v*ln_rs[b,n] - ln_u[m]*ln_mu[b,n]*ln_rs[b,n]  (W.diag(g) applied to RAW columns x equals
+ * W.LN(x) minus the bias term when ln_u = W.g row sums: MGFNLayerNorm over channels, modeling_mgfn.py:36-46);
+ * + bias_m[m] + bias_n[n];  act (0 none, 1 ReLU, 2 GELU-erf);  + beta * residual (C's strides). */
+typedef struct advhip_gemm_desc {
+  int32_t M, N, K, batch;
+  int64_t sAb, sAm, sAk;
+  int64_t sBb, sBk, sBn;
+  int64_t sCb, sCm, sCn;
+  float alpha, beta;
+  int32_t act;
+  const float* bias_m;
+  const float* bias_n;
+  const float* ln_u;
+  const float* ln_mu;
+  const float* ln_rs;
+  const float* residual;
+} advhip_gemm_desc;
+int advhip_bgemm_f32(const advhip_gemm_desc* d, const float* A, const float* B, float* C, void* stream);
+
+/* y[r, :] = softmax(x[r, :] * scale) over rows of n contiguous floats (F.softmax(theta_phi * dim_inner**-0.5, dim=-1),
+ * src/i3d.py:174-175; the attention softmax of GlanceAttention, modeling_mgfn.py:115-120).  x == y allowed. */
+int advhip_softmax_rows_f32(const float* x, float* y, int64_t rows, int32_t n, float scale, void* stream);
+
 /* --- MIL scorer (MGFN head) -----------------------------------------------------------------
  * Fused magnitude / score reduction of magnitude_selection_and_score_prediction
  * (src/models/mgfn/modeling_mgfn.py:314-319): for features (bs*ncrops, T, F) and per-crop scores

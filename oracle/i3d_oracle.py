@@ -60,13 +60,33 @@ def bottleneck(x: torch.Tensor, sd: Dict[str, torch.Tensor], p: str, stride: int
     return F.relu(out + res)
 
 
+def nonlocal_block(x: torch.Tensor, sd: Dict[str, torch.Tensor], p: str) -> torch.Tensor:
+    """NonLocalBlock.forward, src/i3d.py:159-195: embedded-Gaussian attention of every position over the (1,2,2)-pooled
+    positions; theta/phi/g/out are 1x1x1 convs WITH bias (nn.Conv3d default), `out` is followed by eval BatchNorm, the
+    residual is added without a ReLU."""
+    b = x.shape[0]
+    inner = sd[f"{p}.theta.weight"].shape[0]
+    mp = F.max_pool3d(x, kernel_size=(1, 2, 2), stride=(1, 2, 2))                       # :163
+    theta = F.conv3d(x, sd[f"{p}.theta.weight"], sd[f"{p}.theta.bias"])                  # :164
+    phi = F.conv3d(mp, sd[f"{p}.phi.weight"], sd[f"{p}.phi.bias"])                       # :165
+    g = F.conv3d(mp, sd[f"{p}.g.weight"], sd[f"{p}.g.bias"])                             # :166
+    shape5 = theta.shape
+    theta, phi, g = theta.reshape(b, inner, -1), phi.reshape(b, inner, -1), g.reshape(b, inner, -1)
+    att = torch.bmm(theta.transpose(1, 2), phi) * (inner ** -0.5)                        # :171-174
+    att = F.softmax(att, dim=-1)                                                         # :175
+    t = torch.bmm(g, att.transpose(1, 2)).reshape(shape5)                                # :178-179
+    out = F.conv3d(t, sd[f"{p}.out.weight"], sd[f"{p}.out.bias"])                        # :181
+    return _bn(out, sd, f"{p}.bn") + x                                                   # :182-184
+
+
 @torch.no_grad()
 def i3d_forward(
     x: torch.Tensor,
     sd: Dict[str, torch.Tensor],
     tap: Optional[Callable[[str, torch.Tensor], None]] = None,
 ) -> torch.Tensor:
-    """(B,3,T,H,W) fp32 -> (B,2048,1,1,1).  `tap(name, tensor)` sees every stage output."""
+    """(B,3,T,H,W) fp32 -> (B,2048,1,1,1).  `tap(name, tensor)` sees every stage output.  Blocks whose state dict
+    carries `<block>.nl.*` entries (I3Res50(use_nl=True)) are followed by their NonLocalBlock (src/i3d.py:118-119)."""
     t = tap or (lambda n, v: None)
     x = F.conv3d(x, sd["conv1.weight"], None, stride=(2, 2, 2), padding=(2, 3, 3))
     x = F.relu(_bn(x, sd, "bn1"))
@@ -76,6 +96,8 @@ def i3d_forward(
     for name, _planes, stride, temps in STAGES:
         for i, tc in enumerate(temps):
             x = bottleneck(x, sd, f"{name}.{i}", stride if i == 0 else 1, tc, i == 0)
+            if f"{name}.{i}.nl.theta.weight" in sd:
+                x = nonlocal_block(x, sd, f"{name}.{i}.nl")
             t(f"{name}.{i}", x)
         t(name, x)
         if name == "layer1":

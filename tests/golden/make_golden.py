@@ -59,6 +59,8 @@ def _video_io_placeholders():
 
 
 from anomaly_detection_on_video_amd.weights import (  # noqa: E402
+    NONLOCAL_CASES,
+    synth_nonlocal_case,
     synth_i3d_state_dict,
     synth_input,
     synth_module_state_dict,
@@ -168,6 +170,30 @@ def golden_i3d():
         micro[f"{name}_cfg"] = np.array([inpl, planes, stride, tc, int(has_ds), b, t, h, w], dtype=np.int64)
     np.savez_compressed(os.path.join(HERE, "i3d_blocks.npz"), **micro)
     print("i3d_blocks.npz", {k: v.shape for k, v in micro.items() if k.endswith("_y")})
+
+
+def golden_nonlocal():
+    """The reference's own NonLocalBlock (src/i3d.py:124-195) and I3Res50(use_nl=True) -- dead code under the factory's
+    use_nl=False, but importable, so it can be pinned."""
+    from src.i3d import I3Res50, NonLocalBlock  # reference
+
+    out = {}
+    for name in NONLOCAL_CASES:
+        dim, inner, sd, x = synth_nonlocal_case(name)
+        blk = NonLocalBlock(dim, dim, inner).eval()
+        blk.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            out[f"{name}_y"] = blk(x).numpy()
+    model = I3Res50(use_nl=True)
+    sd = synth_i3d_state_dict(use_nl=True)
+    res = model.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    model.eval()
+    with torch.no_grad():
+        out["feat_nl_small"] = model(synth_input((1, 3, 8, 112, 96), 7)).reshape(1, 2048).numpy()
+        out["feat_nl_64"] = model(synth_input((2, 3, 16, 64, 64), 3)).reshape(2, 2048).numpy()
+    np.savez_compressed(os.path.join(HERE, "nonlocal.npz"), **out)
+    print("nonlocal.npz", {k: v.shape for k, v in out.items()})
 
 
 # ------------------------------------------------------------------------------- MGFN
@@ -311,9 +337,11 @@ def golden_host():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["i3d", "mgfn", "host"]
+    which = sys.argv[1:] or ["i3d", "nonlocal", "mgfn", "host"]
     if "i3d" in which:
         golden_i3d()
+    if "nonlocal" in which:
+        golden_nonlocal()
     if "mgfn" in which:
         golden_mgfn()
     if "host" in which:

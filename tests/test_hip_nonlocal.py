@@ -1,0 +1,124 @@
+"""NonLocalBlock / I3Res50(use_nl=True) on the HIP path vs the reference's own outputs (tests/golden/nonlocal.npz, made
+by the reference's NonLocalBlock and I3Res50(use_nl=True), src/i3d.py:124-195) and the CPU oracle; plus the batched GEMM
+and row-softmax entry points they are built from.  Run with -m gpu."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, assert_close_elementwise, rel_err
+from anomaly_detection_on_video_amd.weights import NONLOCAL_CASES, synth_i3d_state_dict, synth_input, synth_nonlocal_case, synth_tensor
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+GEMM_CASES = [
+    # batch, M, N, K, A transposed view?, B transposed view?
+    (2, 96, 48, 256, True, False),     # theta^T . phi      (A row-contiguous in m, B row-contiguous in n)
+    (2, 256, 96, 48, False, True),     # g . p^T            (both k-contiguous)
+    (3, 70, 130, 37, False, False),    # ragged everything, K not a multiple of 4
+    (1, 300, 65, 128, True, True),
+    (1, 1, 7, 5, False, False),
+    (4, 128, 64, 64, False, False),
+    (1, 1024, 4096, 96, False, False),  # big tile path (128 x 64)
+    (1, 2048, 200, 1024, False, True),
+]
+
+
+@pytest.mark.parametrize("case", GEMM_CASES, ids=[str(c) for c in GEMM_CASES])
+def test_bgemm_vs_torch_fp64(case):
+    from anomaly_detection_on_video_amd import ops
+
+    batch, M, N, K, ta, tb = case
+    a = synth_tensor(f"gemm.a{case}", (batch, K, M) if ta else (batch, M, K), scale=1.0)
+    b = synth_tensor(f"gemm.b{case}", (batch, N, K) if tb else (batch, K, N), scale=1.0)
+    av, bv = (a.transpose(1, 2) if ta else a), (b.transpose(1, 2) if tb else b)
+    ref = torch.bmm(av.double(), bv.double())
+    ad, bd = a.to(_dev()), b.to(_dev())
+    adv, bdv = (ad.transpose(1, 2) if ta else ad), (bd.transpose(1, 2) if tb else bd)
+    out = ops.bgemm(adv, bdv)
+    assert rel_err(out.cpu(), ref) < 2e-6
+    # epilogue: alpha, biases, GELU / ReLU, residual, output written through a transposed view
+    bm = synth_tensor(f"gemm.bm{case}", (M,))
+    bn = synth_tensor(f"gemm.bn{case}", (N,))
+    res = synth_tensor(f"gemm.r{case}", (batch, M, N))
+    ref2 = torch.nn.functional.gelu(0.37 * ref + bm.double()[None, :, None] + bn.double()[None, None, :]) + 0.5 * res.double()
+    out2 = ops.bgemm(adv, bdv, alpha=0.37, bias_m=bm.to(_dev()), bias_n=bn.to(_dev()), act=2, residual=res.to(_dev()), beta=0.5)
+    assert rel_err(out2.cpu(), ref2) < 5e-6
+    out_t = torch.empty((batch, N, M), device=_dev())
+    ops.bgemm(adv, bdv, act=1, out=out_t.transpose(1, 2))
+    assert rel_err(out_t.transpose(1, 2).cpu(), torch.relu(ref)) < 2e-6
+    # broadcast batch (stride 0) on B
+    if batch > 1:
+        out3 = ops.bgemm(adv, bdv[:1])
+        assert rel_err(out3.cpu(), torch.matmul(av.double(), bv[:1].double())) < 2e-6
+
+
+def test_bgemm_layernorm_fold_and_softmax_rows():
+    """W.LN(x) with MGFNLayerNorm semantics ((x - mean) / (sqrt(var_biased) + eps) * g + b over channels,
+    modeling_mgfn.py:36-46) as ONE GEMM on the raw x: W.diag(g) as the A operand, u = rowsum(W.diag(g)), column
+    statistics mu / rs in the epilogue, W.b as the row bias."""
+    from anomaly_detection_on_video_amd import ops
+
+    Cout, Cin, Ncol = 192, 128, 330
+    w = synth_tensor("lnf.w", (Cout, Cin), scale=0.2)
+    x = synth_tensor("lnf.x", (Cin, Ncol), scale=2.0, offset=1.5)
+    g = synth_tensor("lnf.g", (Cin,), scale=0.25, offset=1.0)
+    bb = synth_tensor("lnf.b", (Cin,), scale=0.1)
+    xd = x.double()
+    mu = xd.mean(0)
+    std = xd.var(0, unbiased=False).sqrt()
+    ln = (xd - mu) / (std + 1e-5) * g.double()[:, None] + bb.double()[:, None]
+    ref = w.double() @ ln
+    dev = _dev()
+    wg = (w * g[None, :]).to(dev)
+    out = ops.bgemm(wg, x.to(dev), bias_m=(w.double() @ bb.double()).float().to(dev),
+                    ln=(wg.sum(1), mu.float().to(dev), (1.0 / (std + 1e-5)).float().to(dev)))
+    assert rel_err(out[0].cpu(), ref) < 1e-5
+    s = synth_tensor("sm.x", (7, 33, 392), scale=6.0)
+    got = ops.softmax_rows(s.to(dev), scale=0.25)
+    assert rel_err(got.cpu(), torch.softmax(s.double() * 0.25, dim=-1)) < 1e-6
+    assert torch.allclose(got.sum(-1).cpu(), torch.ones(7, 33), atol=1e-5)
+
+
+@pytest.mark.parametrize("name", NONLOCAL_CASES)
+def test_nonlocal_block_vs_reference_golden(name):
+    from anomaly_detection_on_video_amd.i3d import NonLocalBlock
+    from oracle import i3d_oracle
+
+    dim, inner, sd, x = synth_nonlocal_case(name)
+    blk = NonLocalBlock(dim, dim, inner)
+    blk.load_state_dict(sd, strict=True)
+    blk = blk.eval().to(_dev())
+    y = blk(x.to(_dev())).cpu()
+    g = np.load(os.path.join(GOLDEN, "nonlocal.npz"))
+    assert rel_err(y, g[f"{name}_y"]) < 2e-5
+    assert_close_elementwise(y, g[f"{name}_y"], 1e-3, 1e-3)
+    assert rel_err(y, i3d_oracle.nonlocal_block(x, {f"nl.{k}": v for k, v in sd.items()}, "nl")) < 2e-5
+    assert torch.equal(y, blk(x.to(_dev())).cpu())
+
+
+def test_i3res50_with_nonlocal_blocks_vs_reference_golden():
+    from anomaly_detection_on_video_amd.i3d import I3Res50, NonLocalBlock
+
+    m = I3Res50(use_nl=True)
+    sd = synth_i3d_state_dict(use_nl=True)
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict(sd, strict=True)
+    m = m.eval().to(_dev())
+    assert sum(1 for mod in m.modules() if isinstance(mod, NonLocalBlock)) == 5
+    g = np.load(os.path.join(GOLDEN, "nonlocal.npz"))
+    y = m(synth_input((1, 3, 8, 112, 96), 7).to(_dev())).reshape(1, 2048).cpu()
+    assert rel_err(y, g["feat_nl_small"]) < 1e-4
+    y2 = m(synth_input((2, 3, 16, 64, 64), 3).to(_dev())).reshape(2, 2048).cpu()
+    assert rel_err(y2, g["feat_nl_64"]) < 1e-4
+    assert_close_elementwise(y2, g["feat_nl_64"], 1e-3, 1e-3)
+    # a batch that splits over two streams (first-use tables of the non-local convs are built ahead of the fork)
+    x16 = synth_input((2, 3, 16, 64, 64), 3).repeat(8, 1, 1, 1, 1).to(_dev())
+    y16 = m(x16).reshape(16, 2048).cpu()
+    assert rel_err(y16, np.tile(g["feat_nl_64"], (8, 1))) < 1e-4

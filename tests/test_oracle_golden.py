@@ -221,3 +221,26 @@ def test_gt_rule():
     gt = host_oracle.gt_from_annotation(2, (5, 100), (30, 31))
     assert sum(gt) == 27  # clipped at num_frame
     assert sum(host_oracle.gt_from_annotation(2, (-1, -1), (-1, -1))) == 0
+
+
+# ------------------------------------------------------------------------------ NonLocalBlock (I3Res50(use_nl=True))
+def test_nonlocal_block_oracle_vs_reference_golden():
+    """oracle.nonlocal_block vs the reference's own NonLocalBlock outputs (src/i3d.py:124-195)."""
+    from anomaly_detection_on_video_amd.weights import NONLOCAL_CASES, synth_nonlocal_case
+
+    g = np.load(os.path.join(GOLDEN, "nonlocal.npz"))
+    for name in NONLOCAL_CASES:
+        _dim, _inner, sd, x = synth_nonlocal_case(name)
+        y = i3d_oracle.nonlocal_block(x, {f"nl.{k}": v for k, v in sd.items()}, "nl")
+        assert rel_err(y, g[f"{name}_y"]) < 1e-5, name
+
+
+def test_i3d_with_nonlocal_blocks_oracle_vs_reference_golden():
+    from anomaly_detection_on_video_amd.weights import nonlocal_positions, synth_i3d_state_dict
+
+    sd = synth_i3d_state_dict(use_nl=True)
+    assert sum(1 for k in sd if k.endswith(".nl.theta.weight")) == len(nonlocal_positions(True)) == 5
+    g = np.load(os.path.join(GOLDEN, "nonlocal.npz"))
+    y = i3d_oracle.i3d_forward(synth_input((1, 3, 8, 112, 96), 7), sd)
+    assert rel_err(y.reshape(1, 2048), g["feat_nl_small"]) < 1e-5
+    assert np.isfinite(g["feat_nl_64"]).all() and float(np.abs(g["feat_nl_64"]).max()) > 0
