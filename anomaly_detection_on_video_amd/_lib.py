@@ -108,6 +108,7 @@ SIGNATURES = {
     "advhip_mgfn_loss_bwd_f32": (C.c_int, [_P] * 14 + [_I] * 5 + [_P]),
     "advhip_segment_features_f32": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "advhip_add_magnitude_f32": (C.c_int, [_P, _P, _L, _I, _P]),
+    "advhip_tencrop_normalize_u8": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, C.c_float, C.c_float, _P]),
     "advhip_normalize_permute_u8": (C.c_int, [_P, _P, _L, _I, _I, _I, _I, C.c_float, C.c_float, _P]),
 }
 

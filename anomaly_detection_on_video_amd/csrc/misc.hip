@@ -79,9 +79,59 @@ __global__ void normalize_permute_u8_kernel(const uint8_t* __restrict__ x, float
   }
 }
 
+// TenCrop + float + normalise + LoopPad + permute in one pass (src/gtransforms.py:20-73, 115-132; src/dataset.py:175-195;
+// extract_features.py:83): resized uint8 frames (F, H, W, C) -- the HWC bytes a decoder / PIL hands over -- to the backbone's
+// input (n_clips * 10, C, fpc, cs, cs) fp32.  Crop j < 5 of a frame = its (top_j, left_j) window: top-left, top-right,
+// bottom-left, bottom-right, centre (torchvision five_crop order; centre offsets are Python-rounded halves, computed by the
+// caller); crops 5..9 = the same five windows of the horizontally flipped frame: pixel (y, x) = frame[top + y][W - 1 - (left + x)].
+// Frame t of clip c = frames[c * fpc + t % len_c], len_c = min(fpc, F - c * fpc) (LoopPad: a short last clip repeats itself).
+struct CropTable { int top[5], left[5]; };
+
+__global__ void tencrop_normalize_u8_kernel(const uint8_t* __restrict__ x, float* __restrict__ y, int F, int H, int W, int C,
+                                            int fpc, int cs, CropTable ct, float mean, float stdv, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int xo = (int)(i % cs);  // output order: (clip, crop, c, t, y, x)
+    long long r = i / cs;
+    const int yo = (int)(r % cs);
+    r /= cs;
+    const int t = (int)(r % fpc);
+    r /= fpc;
+    const int c = (int)(r % C);
+    r /= C;
+    const int crop = (int)(r % 10);
+    const int clip = (int)(r / 10);
+    const int len = min(fpc, F - clip * fpc);
+    const int f = clip * fpc + t % len;
+    const int j = crop % 5;
+    const int sy = ct.top[j] + yo;
+    const int sx = crop < 5 ? ct.left[j] + xo : W - 1 - (ct.left[j] + xo);
+    const float v = (float)x[(((long long)f * H + sy) * W + sx) * C + c];
+    y[i] = (v - mean) / stdv;
+  }
+}
+
 }  // namespace advhip
 
 using namespace advhip;
+
+extern "C" int advhip_tencrop_normalize_u8(const uint8_t* frames, float* y, int32_t F, int32_t H, int32_t W, int32_t C,
+                                           int32_t frames_per_clip, int32_t crop, float mean, float stdv, void* stream) {
+  ADVHIP_REQUIRE(frames && y && F > 0 && C > 0 && frames_per_clip > 0 && crop > 0, "tencrop_normalize_u8: bad arguments");
+  ADVHIP_REQUIRE(H >= crop && W >= crop, "tencrop_normalize_u8: frames (%d x %d) smaller than the %d crop", H, W, crop);
+  ADVHIP_REQUIRE(stdv != 0.f, "tencrop_normalize_u8: std must be non-zero");
+  // torchvision center_crop: int(round((H - crop) / 2.0)) with Python's round-half-to-even
+  auto half_even = [](int d) { return (d % 2 == 0) ? d / 2 : ((d / 2) % 2 == 0 ? d / 2 : d / 2 + 1); };
+  CropTable ct;
+  const int tops[5] = {0, 0, H - crop, H - crop, half_even(H - crop)};
+  const int lefts[5] = {0, W - crop, 0, W - crop, half_even(W - crop)};
+  for (int j = 0; j < 5; ++j) { ct.top[j] = tops[j]; ct.left[j] = lefts[j]; }
+  const long long n_clips = (F + frames_per_clip - 1) / frames_per_clip;
+  const long long total = n_clips * 10 * C * frames_per_clip * (long long)crop * crop;
+  const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 64);
+  hipLaunchKernelGGL(tencrop_normalize_u8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, y, F, H, W, C,
+                     frames_per_clip, crop, ct, mean, stdv, total);
+  return check_launch("tencrop_normalize_u8");
+}
 
 extern "C" int advhip_normalize_permute_u8(const uint8_t* x, float* y, int64_t N, int32_t T, int32_t C, int32_t H,
                                            int32_t W, float mean, float stdv, void* stream) {

@@ -115,6 +115,27 @@ def extract_video(model, video_clips: torch.Tensor, batch_size: int = 16, **kw) 
     return np.squeeze(out)  # np.squeeze as the reference does (:100): a 1-clip video loses its first axis
 
 
+@torch.no_grad()
+def extract_video_frames(model, frames: torch.Tensor, frames_per_clip: int = FRAMES_PER_CLIP, crop: int = 224,
+                         clips_per_step: int = 3, **kw) -> np.ndarray:
+    """One video as resized uint8 frames (F, H, W, 3) -- what the decoder + GroupResize(256) hand over -- to np.float32
+    (n_clips, 10, 2048): TenCrop, float conversion, normalisation, LoopPad and both permutes run on the device
+    (mil_ops.tencrop_normalize_u8), so only the resized uint8 frames cross PCIe (1/23 of the fp32 ten-crop tensor the
+    reference's DataLoader ships per clip, src/dataset.py:175-195, extract_features.py:79-86).  `clips_per_step` clips
+    (x 10 crops) are pre-processed and run per step."""
+    if frames.dtype != torch.uint8 or frames.dim() != 4:
+        raise ValueError(f"expected uint8 (F,H,W,C) frames, got {frames.dtype} {tuple(frames.shape)}")
+    dev = next(model.parameters()).device
+    rows = []
+    step = clips_per_step * frames_per_clip
+    max_cc = kw.get("max_crop_clips", 32)
+    for f0 in range(0, frames.shape[0], step):
+        x = mil_ops.tencrop_normalize_u8(frames[f0 : f0 + step].to(dev, non_blocking=True), frames_per_clip, crop)
+        rows.append(run_chunks_on_lanes(model, [x[i : i + max_cc] for i in range(0, x.shape[0], max_cc)]))
+    out = torch.cat(rows, dim=0).reshape(-1, NCROPS, 2048).cpu().numpy()
+    return np.squeeze(out)
+
+
 def extract(sources: Iterable[Tuple[str, Callable[[], torch.Tensor]]], model, outpath: str, **kw) -> Dict[str, str]:
     """Per-video driver with the reference's resume rule: skip a video whose `<name>_i3d.npy`
     exists (:106-110).  `sources` yields (name, loader) where loader() returns the clip tensor."""

@@ -183,3 +183,22 @@ def normalize_permute_u8(frames: torch.Tensor, mean: float = PIXEL_MEAN, std: fl
     check(_lib.load().advhip_normalize_permute_u8(ptr(frames), ptr(out), n, t, c, h, w, C_float(mean), C_float(std), stream()),
           "normalize_permute_u8")
     return out
+
+
+def tencrop_normalize_u8(frames: torch.Tensor, frames_per_clip: int = 16, crop: int = 224, mean: float = PIXEL_MEAN,
+                         std: float = PIXEL_STD) -> torch.Tensor:
+    """Resized uint8 frames (F, H, W, C) of one video -> the backbone's input (n_clips * 10, C, frames_per_clip, crop, crop)
+    fp32: TenCrop, float, normalise, LoopPad and the layout permutes of TenCropVideoFrameDataset / _extract
+    (src/dataset.py:175-195, src/gtransforms.py, extract_features.py:83) in one HIP pass.  Row = clip * 10 + crop."""
+    frames = frames.contiguous()
+    require_gpu(frames)
+    if frames.dtype != torch.uint8 or frames.dim() != 4:
+        raise ValueError(f"expected uint8 (F,H,W,C), got {frames.dtype} {tuple(frames.shape)}")
+    f, h, w, c = frames.shape
+    if h < crop or w < crop:
+        raise ValueError(f"frames {h}x{w} smaller than the {crop} crop")
+    n_clips = -(-f // frames_per_clip)
+    out = torch.empty((n_clips * 10, c, frames_per_clip, crop, crop), device=frames.device, dtype=torch.float32)
+    check(_lib.load().advhip_tencrop_normalize_u8(ptr(frames), ptr(out), f, h, w, c, frames_per_clip, crop, C_float(mean), C_float(std),
+                                                  stream()), "tencrop_normalize_u8")
+    return out

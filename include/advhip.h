@@ -258,6 +258,15 @@ int advhip_add_magnitude_f32(const float* feats, float* out, int64_t rows, int32
 int advhip_normalize_permute_u8(const uint8_t* x, float* y, int64_t N, int32_t T, int32_t C,
                                 int32_t H, int32_t W, float mean, float stdv, void* stream);
 
+/* The whole clip pre-processing after the resize, on the device: TenCrop (four corners + centre, then the same five of
+ * the horizontally flipped frame: src/gtransforms.py:20-26 -> torchvision.transforms.TenCrop), PILToTensor().float(),
+ * (x - mean) / std (src/gtransforms.py:57-73), LoopPad(frames_per_clip) (src/gtransforms.py:115-132) and the permutes
+ * of src/dataset.py:195 + extract_features.py:83.
+ *   frames: uint8 (F, H, W, C), the resized frames as decoded (HWC);  y: fp32 (ceil(F / fpc) * 10, C, fpc, crop, crop),
+ *   row = clip * 10 + crop index.  Only the resized uint8 frames cross PCIe: 1/23 of the fp32 ten-crop bytes. */
+int advhip_tencrop_normalize_u8(const uint8_t* frames, float* y, int32_t F, int32_t H, int32_t W, int32_t C,
+                                int32_t frames_per_clip, int32_t crop, float mean, float stdv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,10 @@ that sit either side of the hot path.
     gt_from_annotation /root/reference/make_gt_ucf.py:36-50
     frame_level_auc    /root/reference/src/runner.py:66-76 (sklearn roc_curve/auc, precision_recall_curve/auc)
 
+    ten_crop_clips     /root/reference/src/dataset.py:175-195 + src/gtransforms.py:20-73,115-132 + extract_features.py:83
+                       (TenCrop itself is torchvision.transforms.TenCrop -- third-party, not in the reference tree and not
+                       installed here: its published algorithm is restated, "parity unpinned" for the crop geometry)
+
 Written as explicit python loops on purpose: this is the checker, not the product.
 """
 from __future__ import annotations
@@ -97,3 +101,41 @@ def frame_level_auc(preds_per_video: List[np.ndarray], labels_per_video: List[np
     preds = np.repeat(np.concatenate(preds_per_video), frames_per_clip)
     labels = np.concatenate(labels_per_video)
     return roc_auc(labels, preds), pr_auc(labels, preds)
+
+
+def ten_crop_clips(frames: np.ndarray, frames_per_clip: int = 16, crop: int = 224, mean: float = 114.75, std: float = 57.375) -> np.ndarray:
+    """uint8 (F, H, W, C) resized frames of one video -> float32 (n_clips, 10, C, frames_per_clip, crop, crop): what
+    `TenCropVideoFrameDataset[i]` (src/dataset.py:187-195) followed by `inputs.permute(0,1,3,2,4,5)` (extract_features.py:83)
+    hands to the backbone, for every clip i.
+
+    torchvision.transforms.TenCrop(size) (vertical_flip=False) = five_crop(img) + five_crop(hflip(img));
+    five_crop = (top-left, top-right, bottom-left, bottom-right, center_crop);
+    center_crop offsets = int(round((H - size) / 2.0)), int(round((W - size) / 2.0))  (Python round: half to even).
+    Then PILToTensor().float() (HWC bytes -> CHW float), `t.sub_(mean).div_(std)` per channel in fp32
+    (src/gtransforms.py:69-72), LoopPad (src/gtransforms.py:119-132)."""
+    F, H, W, C = frames.shape
+    m32, s32 = np.float32(mean), np.float32(std)
+
+    def five(img):  # img: (H, W, C)
+        top_c, left_c = int(round((H - crop) / 2.0)), int(round((W - crop) / 2.0))
+        offs = [(0, 0), (0, W - crop), (H - crop, 0), (H - crop, W - crop), (top_c, left_c)]
+        return [img[t : t + crop, l : l + crop] for t, l in offs]
+
+    clips = []
+    for start in range(0, F, frames_per_clip):
+        chunk = frames[start : start + frames_per_clip]
+        per_frame = []
+        for img in chunk:
+            crops = five(img) + five(img[:, ::-1])
+            t = np.stack([c.transpose(2, 0, 1) for c in crops]).astype(np.float32)  # (10, C, crop, crop)
+            per_frame.append((t - m32) / s32)
+        tensor = np.stack(per_frame)  # (len, 10, C, crop, crop)
+        length = tensor.shape[0]
+        if length != frames_per_clip:  # LoopPad
+            n_pad = frames_per_clip - length
+            pad = [tensor] * (n_pad // length)
+            if n_pad % length > 0:
+                pad.append(tensor[0 : n_pad % length])
+            tensor = np.concatenate([tensor] + pad, axis=0)
+        clips.append(tensor.transpose(1, 2, 0, 3, 4))  # (10, C, T, crop, crop)
+    return np.stack(clips).astype(np.float32)
