@@ -97,6 +97,7 @@ SIGNATURES = {
     "advhip_bgemm_f32": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P]),
     "advhip_softmax_rows_f32": (C.c_int, [_P, _P, _L, _I, C.c_float, _P]),
     "advhip_maxpool3d_f32": (C.c_int, [_P, _P] + [_I] * 11 + [_P]),
+    "advhip_maxpool3d_padded_f32": (C.c_int, [_P, _P] + [_I] * 14 + [_P]),
     "advhip_maxpool3d_strided_f32": (C.c_int, [_P, _P, _L] + [_I] * 11 + [_P]),
     "advhip_global_avgpool_f32": (C.c_int, [_P, _P, _L, _I, _P]),
     "advhip_mil_magnitude_f32": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

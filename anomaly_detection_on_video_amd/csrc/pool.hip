@@ -12,9 +12,10 @@ namespace advhip {
 // reads of neighbouring threads overlap and are served by L1/L2).
 // `ypad` = extra elements between consecutive samples of y (0 when dense; y may be a channel slice of a wider tensor);
 // `per_sample` = C*To*Ho*Wo.
+// (pt, ph, pw): implicit -inf padding on both sides of each axis (nn.MaxPool3d's padding).
 __global__ void maxpool3d_kernel(const float* __restrict__ x, float* __restrict__ y, int T, int H, int W, int To,
-                                 int Ho, int Wo, int kt, int kh, int kw, int st, int sh, int sw, long long total,
-                                 long long per_sample, long long ypad) {
+                                 int Ho, int Wo, int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw,
+                                 long long total, long long per_sample, long long ypad) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int wo = (int)(i % Wo);
@@ -23,12 +24,15 @@ __global__ void maxpool3d_kernel(const float* __restrict__ x, float* __restrict_
     r /= Ho;
     const int to = (int)(r % To);
     const long long bc = r / To;
-    const float* p = x + ((bc * T + (long long)to * st) * H + (long long)ho * sh) * W + (long long)wo * sw;
+    const int t0 = to * st - pt, h0 = ho * sh - ph, w0 = wo * sw - pw;
+    const float* p = x + bc * T * (long long)H * W;
     float m = -INFINITY;
     for (int a = 0; a < kt; ++a)
       for (int b = 0; b < kh; ++b)
         for (int c = 0; c < kw; ++c) {
-          const float v = p[((long long)a * H + b) * W + c];
+          const int t = t0 + a, h = h0 + b, w = w0 + c;
+          if ((unsigned)t >= (unsigned)T || (unsigned)h >= (unsigned)H || (unsigned)w >= (unsigned)W) continue;
+          const float v = p[((long long)t * H + h) * W + w];
           // torch's max pooling propagates NaN
           m = (v > m || v != v) ? v : m;
         }
@@ -122,6 +126,22 @@ extern "C" int advhip_maxpool3d_f32(const float* x, float* y, int32_t B, int32_t
   return advhip_maxpool3d_strided_f32(x, y, 0, B, C, T, H, W, kt, kh, kw, st, sh, sw, stream);
 }
 
+extern "C" int advhip_maxpool3d_padded_f32(const float* x, float* y, int32_t B, int32_t C, int32_t T, int32_t H, int32_t W,
+                                           int32_t kt, int32_t kh, int32_t kw, int32_t st, int32_t sh, int32_t sw, int32_t pt,
+                                           int32_t ph, int32_t pw, void* stream) {
+  ADVHIP_REQUIRE(x && y, "maxpool3d_padded: null pointer");
+  ADVHIP_REQUIRE(B > 0 && C > 0 && kt > 0 && kh > 0 && kw > 0 && st > 0 && sh > 0 && sw > 0 && pt >= 0 && ph >= 0 && pw >= 0 &&
+                     2 * pt <= kt && 2 * ph <= kh && 2 * pw <= kw && T + 2 * pt >= kt && H + 2 * ph >= kh && W + 2 * pw >= kw,
+                 "maxpool3d_padded: bad shape (T=%d H=%d W=%d k=%d,%d,%d s=%d,%d,%d p=%d,%d,%d; padding at most half the window)", T, H, W,
+                 kt, kh, kw, st, sh, sw, pt, ph, pw);
+  const int To = (T + 2 * pt - kt) / st + 1, Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
+  const long long total = (long long)B * C * To * Ho * Wo;
+  const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(maxpool3d_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, T, H, W, To, Ho, Wo, kt, kh, kw, st, sh,
+                     sw, pt, ph, pw, total, total, 0ll);
+  return check_launch("maxpool3d_padded");
+}
+
 extern "C" int advhip_maxpool3d_strided_f32(const float* x, float* y, int64_t y_batch_stride, int32_t B, int32_t C, int32_t T,
                                             int32_t H, int32_t W, int32_t kt, int32_t kh, int32_t kw, int32_t st, int32_t sh,
                                             int32_t sw, void* stream) {
@@ -149,7 +169,7 @@ extern "C" int advhip_maxpool3d_strided_f32(const float* x, float* y, int64_t y_
   }
   const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 32);
   hipLaunchKernelGGL(maxpool3d_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, T, H, W, To, Ho, Wo, kt, kh,
-                     kw, st, sh, sw, total, per_sample, ypad);
+                     kw, st, sh, sw, 0, 0, 0, total, per_sample, ypad);
   return check_launch("maxpool3d");
 }
 

@@ -454,18 +454,19 @@ def build_i3d_feature_extractor(
     if model_name == "tushar-n-baseline":
         model = I3Res50(use_nl=False)
     elif model_name == "i3d_8x8_r50":
-        raise NotImplementedError(
-            "i3d_8x8_r50 is pytorchvideo's create_resnet (third-party, not vendored in the reference; "
-            "parity unpinned) -- see DESIGN.md 'next rows'. Use model_name='tushar-n-baseline'."
-        )
+        # pytorchvideo's create_resnet topology on the same kernels; PARITY UNPINNED (third-party arithmetic that is
+        # neither vendored in the reference nor installed here): see i3d_ptv.py
+        from .i3d_ptv import I3D8x8R50
+
+        model = I3D8x8R50()
     else:
         raise AttributeError
 
     path = state_dict_path or os.environ.get("ADV_I3D_WEIGHTS")
     if path is None and os.environ.get("ADV_I3D_SYNTHETIC") == "1":
-        from .weights import synth_i3d_state_dict
+        from .weights import synth_i3d_state_dict, synth_module_state_dict
 
-        sd = synth_i3d_state_dict()
+        sd = synth_i3d_state_dict() if model_name == "tushar-n-baseline" else synth_module_state_dict(model, gain=2.0)
     else:
         if path is None:
             from huggingface_hub import hf_hub_download

@@ -265,12 +265,20 @@ def conv3d_bn_act_maxpool211(x: torch.Tensor, pc: PackedConv, relu: bool = True,
     return y
 
 
-def maxpool3d(x: torch.Tensor, kernel, stride, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """`out`: optional destination, contiguous or a channel slice of a wider NCDHW tensor."""
+def maxpool3d(x: torch.Tensor, kernel, stride, out: Optional[torch.Tensor] = None, padding=(0, 0, 0)) -> torch.Tensor:
+    """`out`: optional destination, contiguous or a channel slice of a wider NCDHW tensor (un-padded pooling only)."""
     require_gpu(x)
     require_gpu(out, contiguous=False)
     B, Cc, T, H, W = x.shape
     k, s = _triple(kernel), _triple(stride)
+    p = _triple(padding)
+    if any(p):
+        if out is not None:
+            raise ValueError("maxpool3d: `out` is not supported together with padding")
+        to, ho, wo = conv_out_dims((T, H, W), k, s, p)
+        y = torch.empty((B, Cc, to, ho, wo), device=x.device, dtype=torch.float32)
+        check(_lib.load().advhip_maxpool3d_padded_f32(ptr(x), ptr(y), B, Cc, T, H, W, *k, *s, *p, stream()), "maxpool3d_padded")
+        return y
     to, ho, wo = conv_out_dims((T, H, W), k, s, (0, 0, 0))
     y = out if out is not None else torch.empty((B, Cc, to, ho, wo), device=x.device, dtype=torch.float32)
     if tuple(y.shape) != (B, Cc, to, ho, wo):

@@ -156,6 +156,12 @@ int advhip_maxpool3d_f32(const float* x, float* y, int32_t B, int32_t C, int32_t
                          int32_t W, int32_t kt, int32_t kh, int32_t kw, int32_t st, int32_t sh,
                          int32_t sw, void* stream);
 
+/* nn.MaxPool3d with padding (implicit -inf, at most half the window; floor mode): the stem pool k(1,3,3) s(1,2,2) p(0,1,1)
+ * of the pytorchvideo ResNet that `i3d_8x8_r50` names (src/i3d.py:339-350).  Dense x and y. */
+int advhip_maxpool3d_padded_f32(const float* x, float* y, int32_t B, int32_t C, int32_t T, int32_t H, int32_t W, int32_t kt,
+                                int32_t kh, int32_t kw, int32_t st, int32_t sh, int32_t sw, int32_t pt, int32_t ph, int32_t pw,
+                                void* stream);
+
 /* The same, y being a channel slice of a wider tensor (y_batch_stride in elements, 0 = dense). */
 int advhip_maxpool3d_strided_f32(const float* x, float* y, int64_t y_batch_stride, int32_t B, int32_t C, int32_t T, int32_t H,
                                  int32_t W, int32_t kt, int32_t kh, int32_t kw, int32_t st, int32_t sh, int32_t sw, void* stream);

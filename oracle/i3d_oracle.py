@@ -158,3 +158,35 @@ def conv_macs(in_shape: Tuple[int, int, int, int, int] = (1, 3, 16, 224, 224)) -
         if name == "layer1":
             t = (t - 2) // 2 + 1
     return total
+
+
+# ---- `i3d_8x8_r50` (pytorchvideo create_resnet as called at src/i3d.py:339-350): PARITY UNPINNED ------------------------
+# pytorchvideo 0.1.3 is third-party, not vendored in the reference and not installed here; this restates its published
+# topology (see anomaly_detection_on_video_amd/i3d_ptv.py's header) in plain torch ops with pytorchvideo's state-dict
+# keys.  It pins the HIP kernels on that topology, not pytorchvideo itself.
+PTV_CONV_A_KT = ((3, 3, 3), (3, 1, 3, 1), (3, 1, 3, 1, 3, 1), (1, 3, 1))
+
+
+@torch.no_grad()
+def ptv_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor]) -> torch.Tensor:
+    def bn(v, p):
+        return F.batch_norm(v, sd[f"{p}.running_mean"], sd[f"{p}.running_var"], sd[f"{p}.weight"], sd[f"{p}.bias"], training=False, eps=BN_EPS)
+
+    x = F.relu(bn(F.conv3d(x, sd["blocks.0.conv.weight"], None, stride=(1, 2, 2), padding=(2, 3, 3)), "blocks.0.norm"))
+    x = F.max_pool3d(x, (1, 3, 3), (1, 2, 2), padding=(0, 1, 1))
+    bi = 1
+    for si, kts in enumerate(PTV_CONV_A_KT):
+        for ri, kt in enumerate(kts):
+            p = f"blocks.{bi}.res_blocks.{ri}"
+            s = 2 if (si > 0 and ri == 0) else 1
+            h = F.relu(bn(F.conv3d(x, sd[f"{p}.branch2.conv_a.weight"], None, padding=(kt // 2, 0, 0)), f"{p}.branch2.norm_a"))
+            h = F.relu(bn(F.conv3d(h, sd[f"{p}.branch2.conv_b.weight"], None, stride=(1, s, s), padding=(0, 1, 1)), f"{p}.branch2.norm_b"))
+            h = bn(F.conv3d(h, sd[f"{p}.branch2.conv_c.weight"], None), f"{p}.branch2.norm_c")
+            if f"{p}.branch1_conv.weight" in sd:
+                x = bn(F.conv3d(x, sd[f"{p}.branch1_conv.weight"], None, stride=(1, s, s)), f"{p}.branch1_norm")
+            x = F.relu(h + x)
+        bi += 1
+        if si == 0:
+            x = F.max_pool3d(x, (2, 1, 1), (2, 1, 1))
+            bi += 1
+    return F.adaptive_avg_pool3d(F.avg_pool3d(x, (4, 7, 7), stride=1), 1)

@@ -161,3 +161,30 @@ def test_extract_from_resized_uint8_frames_matches_tencrop_tensor_path():
     b = extract.extract_video(m, torch.from_numpy(clips).permute(0, 1, 3, 2, 4, 5).contiguous())
     assert a.shape == b.shape == (2, 10, 2048)
     assert rel_err(a, b) < 1e-5
+
+
+# ------------------------------------------------------------------------------ i3d_8x8_r50 (parity unpinned)
+def test_i3d_8x8_r50_topology_vs_torch_restatement(monkeypatch):
+    """`build_i3d_feature_extractor("i3d_8x8_r50")`: pytorchvideo's create_resnet topology on the HIP kernels, against a
+    plain-torch restatement of the same topology (oracle.ptv_forward).  PARITY UNPINNED against pytorchvideo itself
+    (third-party, absent from the reference tree and from this image): this pins the kernels on that topology only."""
+    from anomaly_detection_on_video_amd.i3d import build_i3d_feature_extractor
+    from anomaly_detection_on_video_amd.weights import synth_module_state_dict
+    from oracle import i3d_oracle
+
+    monkeypatch.setenv("ADV_I3D_SYNTHETIC", "1")
+    m = build_i3d_feature_extractor("i3d_8x8_r50", check_model_size=False, strict=True)
+    keys = list(m.state_dict().keys())
+    assert keys[0] == "blocks.0.conv.weight" and "blocks.1.res_blocks.0.branch1_conv.weight" in keys
+    assert "blocks.3.res_blocks.3.branch2.conv_c.weight" in keys and "blocks.5.res_blocks.2.branch2.norm_c.running_var" in keys
+    assert sum(1 for k in keys if k.endswith("conv.weight") or "conv_" in k and k.endswith(".weight") or k.endswith("branch1_conv.weight")) == 53
+    sd = synth_module_state_dict(m, gain=2.0)
+    m = m.eval().to(_dev())
+    for shape, seed in (((1, 3, 8, 224, 224), 4), ((2, 3, 16, 232, 240), 9)):
+        x = synth_input(shape, seed)
+        y = m(x.to(_dev())).cpu()
+        ref = i3d_oracle.ptv_forward(x, sd)
+        assert y.shape == ref.shape == (shape[0], 2048, 1, 1, 1)
+        assert rel_err(y, ref) < 1e-4, shape
+    with pytest.raises(ValueError):
+        m(synth_input((1, 3, 4, 224, 224), 0).to(_dev()))  # T = 2 after the stage-1 pool: smaller than the head's (4,7,7) window
