@@ -298,7 +298,7 @@ def main():
                       "frac_of_f32_mfma_peak": round(tflop / ms * 1e3 / PEAK_F32_MFMA_TFLOPS, 4)}
         scorer.eval()
 
-    h2d = h2d_u8 = None
+    h2d = h2d_u8 = h2d_frames = None
     if args.h2d and world == 1:  # single-process extra; with N > 1 a rank-0-only step would leave the collective hanging
         # host buffers every step: the copy (and the uint8 pre-processing) is issued on the step's lane, so PCIe
         # transfers overlap the other lanes' compute
@@ -316,6 +316,11 @@ def main():
             torch.cuda.synchronize()
             return args.batch * args.steps / (time.perf_counter() - t1)
 
+        # resized uint8 frames (what a decoder + GroupResize(256) hand over) + TenCrop / normalise / LoopPad / permutes on
+        # the device: 4 clips (64 frames of 256 x 341 x 3) are shipped per step and the first 32 of their 40 crop-clips run
+        # (the stream's batch), so the PCIe side is overstated by 25 % -- conservative
+        fr = torch.randint(0, 256, (64, 256, 341, 3), dtype=torch.uint8).pin_memory()
+        h2d_frames = timed(fr, lambda h: mil_ops.tencrop_normalize_u8(h.to(dev, non_blocking=True))[: args.batch])
         h2d = timed(x.cpu().pin_memory(), lambda h: h.to(dev, non_blocking=True))
         # uint8 pixels over PCIe + on-device normalise/permute (4x fewer bytes)
         xu = torch.randint(0, 256, (args.batch, 16, 3, 224, 224), dtype=torch.uint8).pin_memory()
@@ -363,6 +368,7 @@ def main():
         if h2d is not None:
             out["pcie_inclusive_clips_per_s"] = round(h2d, 2)
             out["pcie_inclusive_uint8_clips_per_s"] = round(h2d_u8, 2)
+            out["pcie_inclusive_resized_frames_u8_clips_per_s"] = round(h2d_frames, 2)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
