@@ -69,6 +69,10 @@ _I = C.c_int32
 _L = C.c_int64
 
 
+class ConvEpilogue(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("y_preact", "dact_z", "ln_u", "ln_mu", "ln_rs")]
+
+
 class GemmDesc(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ("M", "N", "K", "batch")]
                 + [(n, C.c_int64) for n in ("sAb", "sAm", "sAk", "sBb", "sBk", "sBn", "sCb", "sCm", "sCn")]
@@ -95,7 +99,10 @@ SIGNATURES = {
     "advhip_conv3d_bn_relu_maxpool233_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P]),
     "advhip_conv3d_bn_act_maxpool211_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _L, _P, _P, _P, _P, _P, _P, _L, _P]),
     "advhip_bgemm_f32": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P]),
+    "advhip_gemm_nt_f32": (C.c_int, [_P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _L, _P]),
     "advhip_softmax_rows_f32": (C.c_int, [_P, _P, _L, _I, C.c_float, _P]),
+    "advhip_conv3d_bn_act_ex_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _L, _P, _P, _P, _P, _P, _P, _L, C.POINTER(ConvEpilogue), _P, _L, _P]),
+    "advhip_chan_stats_f32": (C.c_int, [_P, _P, _P, _I, _L, C.c_float, _P]),
     "advhip_maxpool3d_f32": (C.c_int, [_P, _P] + [_I] * 11 + [_P]),
     "advhip_maxpool3d_padded_f32": (C.c_int, [_P, _P] + [_I] * 14 + [_P]),
     "advhip_maxpool3d_strided_f32": (C.c_int, [_P, _P, _L] + [_I] * 11 + [_P]),

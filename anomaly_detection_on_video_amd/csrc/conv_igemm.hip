@@ -75,7 +75,14 @@ struct ConvArgs {
   int M, Kpad;
   int THWo, HWo, HW, THW;
   int tiles_m, tiles_n;
-  int relu, vw;
+  int relu, vw;       // relu: activation code 0 none, 1 ReLU, 2 GELU (erf)
+  float* y2;          // nullable: the pre-activation value (after scale/shift/residual), y's addressing -- saved for backward
+  const float* dact;  // nullable: z of a GELU, y's addressing (dense): the result is multiplied by gelu'(z) (fused GELU backward)
+  // nullable LayerNorm fold (1x1x1 convs over a (C, positions) activation): conv(W.diag(g), x_raw) -> W.LN(x) - W.b:
+  //   v = acc * ln_rs[m] - ln_u[n] * ln_mu[m] * ln_rs[m]   before scale / shift (ln_u = row sums of W.diag(g))
+  const float* ln_u;
+  const float* ln_mu;
+  const float* ln_rs;
   int splits;         // 1 = fused epilogue; >1 = K cut into that many slices
   long long slab;     // elements per split-K slab (two-launch form: raw partial sums in y, reduced by splitk_reduce_kernel)
   // in-kernel reduction (LDS-DMA kernels): every (tile, slice) workgroup publishes its partial tile, draws a ticket on the
@@ -131,6 +138,13 @@ struct IgemmCfg {
   static constexpr int SMEM_FLOATS = AB_FLOATS > ST_FLOATS ? AB_FLOATS : ST_FLOATS;
 };
 
+__device__ __forceinline__ float act_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+// d/dx of 0.5 x (1 + erf(x / sqrt 2)) = 0.5 (1 + erf(x / sqrt 2)) + x exp(-x^2 / 2) / sqrt(2 pi)
+__device__ __forceinline__ float act_gelu_grad(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * expf(-0.5f * x * x) * 0.39894228040143267794f;
+}
+__device__ __forceinline__ float act_apply(int code, float v) { return code == 1 ? fmaxf(v, 0.f) : (code == 2 ? act_gelu(v) : v); }
+
 // ---- epilogue shared by both implicit-GEMM kernels -------------------------------------------
 // accumulator element acc[jm][jn][r] of lane (li, lg):
 //   m = m0 + wm*WM + FM*(4*lg + r) + jm,   n = n0 + wn*WN + FN*li + jn
@@ -181,6 +195,14 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[B
           const size_t oy = fused ? (size_t)bb * a.y_bstride + (size_t)n * a.THWo + pp : o;  // output proper
           if (fused) {
             const float sc = a.scale[n], sf = a.shift[n];
+            if (a.ln_u) {  // positions mm .. mm+3 of the flattened (b, t, h, w) index
+              float rs[4], mu[4];
+              vec_load<4>(a.ln_rs + mm, rs);
+              vec_load<4>(a.ln_mu + mm, mu);
+              const float u = a.ln_u[n];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = v[e] * rs[e] - u * (mu[e] * rs[e]);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] * sc + sf;
             if (a.res) {
@@ -189,9 +211,16 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[B
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] += rv[e];
             }
+            if (a.y2) vec_store<4>(a.y2 + oy, v);
             if (a.relu) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+              for (int e = 0; e < 4; ++e) v[e] = act_apply(a.relu, v[e]);
+            }
+            if (a.dact) {
+              float zv[4];
+              vec_load<4>(a.dact + o, zv);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= act_gelu_grad(zv[e]);
             }
           }
           vec_store<4>(yout + oy, v);
@@ -227,6 +256,11 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[B
           for (int e = 0; e < VW; ++e) vals[e] = acc[v0 + e][jn][r];
           if (fused) {
             const float sc = a.scale[n], sf = a.shift[n];
+            if (a.ln_u) {
+              const float u = a.ln_u[n];
+#pragma unroll
+              for (int e = 0; e < VW; ++e) vals[e] = vals[e] * a.ln_rs[mm + e] - u * (a.ln_mu[mm + e] * a.ln_rs[mm + e]);
+            }
 #pragma unroll
             for (int e = 0; e < VW; ++e) vals[e] = vals[e] * sc + sf;
             if (a.res) {
@@ -235,9 +269,16 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[B
 #pragma unroll
               for (int e = 0; e < VW; ++e) vals[e] += rv[e];
             }
+            if (a.y2) vec_store<VW>(a.y2 + oy, vals);
             if (a.relu) {
 #pragma unroll
-              for (int e = 0; e < VW; ++e) vals[e] = fmaxf(vals[e], 0.f);
+              for (int e = 0; e < VW; ++e) vals[e] = act_apply(a.relu, vals[e]);
+            }
+            if (a.dact) {
+              float zv[VW];
+              vec_load<VW>(a.dact + o, zv);
+#pragma unroll
+              for (int e = 0; e < VW; ++e) vals[e] *= act_gelu_grad(zv[e]);
             }
           }
           vec_store<VW>(yout + oy, vals);
@@ -1044,6 +1085,128 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
 }
 
 // ================================================================================================
+// C[s][m][n] = sum_{k in slice s} A[m][k] * B[n][k]: both operands k-contiguous ("NT" product), e.g. the weight gradient
+// dW[o][c] = sum_n dY[o][n] X[c][n] of a GEMM-shaped layer whose activations are stored (channel, position).  Operand
+// tiles are plain row copies [rows][16 k] made by 16-byte LDS-DMA (4 lanes per 64-byte row piece, 16 rows per
+// wave-instruction, LDS image linear in the lane index), 2-deep ring, one barrier per k-tile.  One ds_read_b128 per
+// lane along k gives the operands of FOUR MFMAs: with lane = (row li, k-chunk lg) holding k = 4 lg + e in element e,
+// MFMA e contracts over the k set {e, 4+e, 8+e, 12+e} -- the same set for A and B, so the sum over e covers the k-tile.
+// 64-byte rows make those reads conflict-free (the image is linear in (li, lg)).  Fragment i of a wave = rows 16 i .. 16 i + 15.
+struct GemmKKArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;          // K % 16 == 0
+  int lda, ldb, ldc;    // row pitches in elements
+  unsigned a_bytes, b_bytes;
+  int tiles_m, tiles_n, splits;
+  long long slab;       // elements between the outputs of consecutive K slices
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_kk_dma_kernel(const GemmKKArgs g) {
+  constexpr int BK = 16, FM = BM / 32, FN = BN / 32;
+  constexpr int STAGE = (BM + BN) * BK;  // floats
+  constexpr int LA = BM * 4 / 256, LB = BN * 4 / 256;  // 16-byte LDS-DMA instructions per wave per k-tile
+  static_assert(LA >= 1 && LB >= 1, "tile too small");
+  // the 16-byte LDS-DMA form exists on gfx950 only: hipcc's HOST pass (which merely parses this body) silently drops the
+  // kernel's launch stub when it meets it in a template-dependent statement, so the host pass sees the 4-byte form
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int DMA_BYTES = 16;
+#else
+  constexpr int DMA_BYTES = 4;
+#endif
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int it = xcd_remap((int)blockIdx.x, ntiles * g.splits);
+  const int L = it / g.splits, split = it - L * g.splits;
+  const int tile_m = L / g.tiles_n, tile_n = L - tile_m * g.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, g.a_bytes, 0x00020000);
+  const auto rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, g.b_bytes, 0x00020000);
+  // lane -> (row, 16-byte chunk) of the piece its wave copies: rows beyond M / N fall outside the buffer range -> zeros
+  unsigned avoff[LA], bvoff[LB];
+#pragma unroll
+  for (int j = 0; j < LA; ++j) {
+    const int row = (wave * LA + j) * 16 + (lane >> 2);
+    avoff[j] = (m0 + row < g.M) ? (unsigned)(((m0 + row) * g.lda + (lane & 3) * 4) * 4) : 0xFFFFFF00u;
+  }
+#pragma unroll
+  for (int j = 0; j < LB; ++j) {
+    const int row = (wave * LB + j) * 16 + (lane >> 2);
+    bvoff[j] = (n0 + row < g.N) ? (unsigned)(((n0 + row) * g.ldb + (lane & 3) * 4) * 4) : 0xFFFFFF00u;
+  }
+  auto issue = [&](int kt, int stage) {
+    float* As = smem + stage * STAGE;
+    float* Bs = As + BM * BK;
+#pragma unroll
+    for (int j = 0; j < LA; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(As + (wave * LA + j) * 16 * BK), DMA_BYTES, avoff[j], kt * BK * 4, 0, 0);
+#pragma unroll
+    for (int j = 0; j < LB; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(Bs + (wave * LB + j) * 16 * BK), DMA_BYTES, bvoff[j], kt * BK * 4, 0, 0);
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lg = lane >> 4;
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+  const unsigned a_addr0 = lds0 + (unsigned)(((wm * (BM / 2) + li) * BK + 4 * lg) * 4);
+  const unsigned b_addr0 = lds0 + (unsigned)((BM * BK + (wn * (BN / 2) + li) * BK + 4 * lg) * 4);
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk_all = g.K / BK;
+  const int kt0 = (nk_all * split) / g.splits, kt1 = (nk_all * (split + 1)) / g.splits;
+  if (kt0 < kt1) issue(kt0, 0);
+  int stage = 0;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");  // tile kt is in LDS for every wave; the other stage is free
+    if (kt + 1 < kt1) issue(kt + 1, stage ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned aa = a_addr0 + (unsigned)(stage * STAGE * 4), ba = b_addr0 + (unsigned)(stage * STAGE * 4);
+    Frag<4> fa[FM], fb[FN];
+    [&]<int... I>(std::integer_sequence<int, I...>) { (lds_read<4, I * 16 * BK * 4>(fa[I], aa), ...); }(std::make_integer_sequence<int, FM>{});
+    [&]<int... J>(std::integer_sequence<int, J...>) { (lds_read<4, J * 16 * BK * 4>(fb[J], ba), ...); }(std::make_integer_sequence<int, FN>{});
+    if constexpr (FM == 2 && FN == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0].v), "+v"(fa[1].v), "+v"(fb[0].v), "+v"(fb[1].v));
+    else if constexpr (FM == 4 && FN == 2)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0].v), "+v"(fa[1].v), "+v"(fa[2].v), "+v"(fa[3].v), "+v"(fb[0].v), "+v"(fb[1].v));
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0].v), "+v"(fa[1].v), "+v"(fa[2].v), "+v"(fa[3].v), "+v"(fb[0].v), "+v"(fb[1].v), "+v"(fb[2].v), "+v"(fb[3].v));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].v[e], fb[j].v[e], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    stage ^= 1;
+  }
+  // D[row = 4 lg + r][col = li] of fragment (i, j): m = m0 + wm*BM/2 + 16 i + 4 lg + r, n = n0 + wn*BN/2 + 16 j + li
+  float* __restrict__ C = g.C + (long long)split * g.slab;
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * (BM / 2) + 16 * i + 4 * lg + r;
+      if (m >= g.M) continue;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn * (BN / 2) + 16 * j + li;
+        if (n < g.N) C[(long long)m * g.ldc + n] = acc[i][j][r];
+      }
+    }
+}
+
+// ================================================================================================
 // Split-bf16 variant ("bf16x3"): every fp32 operand is split into two bf16 terms, x = hi + lo (+ <= 2^-17 |x|), and
 // the contraction runs as three bf16 MFMAs per fragment -- hi*hi + hi*lo + lo*hi -- accumulated in fp32
 // (v_mfma_f32_16x16x32_bf16: 8192 MACs in 16 cycles, 16x the fp32 MFMA rate, so 3 of them cost 3/16 of the fp32
@@ -1250,7 +1413,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* 
         const float4 r = reinterpret_cast<const float4*>(res)[i];
         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
       }
-      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      if (relu) { o.x = act_apply(relu, o.x); o.y = act_apply(relu, o.y); o.z = act_apply(relu, o.z); o.w = act_apply(relu, o.w); }
       reinterpret_cast<float4*>(y)[i] = o;
     }
   } else {
@@ -1261,7 +1424,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* 
       const int c = (int)((i / THWo) % Cout);
       float o = s * scale[c] + shift[c];
       if (res) o += res[i];
-      if (relu) o = fmaxf(o, 0.f);
+      if (relu) o = act_apply(relu, o);
       y[i] = o;
     }
   }
@@ -1511,12 +1674,28 @@ extern "C" int advhip_conv3d_bn_act_strided_f32(const advhip_conv3d_desc* d, con
                                                 const float* shift, const float* residual, float* y,
                                                 int64_t y_batch_stride, void* workspace, int64_t workspace_bytes,
                                                 void* stream) {
+  return advhip_conv3d_bn_act_ex_f32(d, x, x_batch_stride, w_packed, ktab, scale, shift, residual, y, y_batch_stride, nullptr,
+                                     workspace, workspace_bytes, stream);
+}
+
+extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const float* x, int64_t x_batch_stride,
+                                           const float* w_packed, const int32_t* ktab, const float* scale, const float* shift,
+                                           const float* residual, float* y, int64_t y_batch_stride,
+                                           const advhip_conv3d_epilogue* ep, void* workspace, int64_t workspace_bytes,
+                                           void* stream) {
   if (int rc = validate(d)) return rc;
+  float* y_preact = ep ? ep->y_preact : nullptr;
+  const float* dact_z = ep ? ep->dact_z : nullptr;
+  const bool ln = ep && ep->ln_u;
+  ADVHIP_REQUIRE(!ep || (!ep->ln_u == !ep->ln_mu && !ep->ln_u == !ep->ln_rs), "conv3d: the LayerNorm fold needs ln_u, ln_mu and ln_rs together");
+  ADVHIP_REQUIRE(d->relu >= 0 && d->relu <= 2, "conv3d: unknown activation code %d (0 none, 1 ReLU, 2 GELU)", d->relu);
   ADVHIP_REQUIRE(x && w_packed && ktab && scale && shift && y, "conv3d: null pointer");
   const Geometry g = geometry(d);
   ConvArgs a;
   a.x = x; a.w = w_packed; a.ktab = reinterpret_cast<const int4*>(ktab);
   a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+  a.y2 = y_preact; a.dact = dact_z;
+  a.ln_u = ln ? ep->ln_u : nullptr; a.ln_mu = ln ? ep->ln_mu : nullptr; a.ln_rs = ln ? ep->ln_rs : nullptr;
   a.B = d->B; a.Cin = d->Cin; a.T = d->T; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
   a.st = d->st; a.sh = d->sh; a.sw = d->sw; a.pt = d->pt; a.ph = d->ph; a.pw = d->pw;
   a.To = g.To; a.Ho = g.Ho; a.Wo = g.Wo;
@@ -1544,12 +1723,17 @@ extern "C" int advhip_conv3d_bn_act_strided_f32(const advhip_conv3d_desc* d, con
   auto aligned_to = [&](int v) {
     const uintptr_t bytes = (uintptr_t)v * sizeof(float);
     return a.THWo % v == 0 && ybs % v == 0 && (uintptr_t)y % bytes == 0 && (uintptr_t)residual % bytes == 0 &&
-           (uintptr_t)workspace % bytes == 0;
+           (uintptr_t)workspace % bytes == 0 && (uintptr_t)y_preact % bytes == 0 && (uintptr_t)dact_z % bytes == 0 &&
+           (uintptr_t)a.ln_mu % bytes == 0 && (uintptr_t)a.ln_rs % bytes == 0;
   };
   a.vw = aligned_to(4) ? 4 : (aligned_to(2) ? 2 : 1);
 
   Choice c = choose(d, M, g.Kpad);
   if (ybs != y_dense && !reduces_in_kernel(c.algo)) c.splits = 1;  // the separate split-K reduce pass writes a dense y
+  ADVHIP_REQUIRE(!ln || (d->kt == 1 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->ph == 0 && d->pw == 0),
+                 "conv3d: the LayerNorm fold applies to 1x1x1 stride-1 convs (per-position statistics of the input)");
+  ADVHIP_REQUIRE((y_preact == nullptr && dact_z == nullptr && !ln) || c.splits == 1 || reduces_in_kernel(c.algo),
+                 "conv3d: pre-activation output / GELU-backward multiplier need a fused epilogue (algo %d with %d splits reduces in a second launch)", c.algo, c.splits);
   int BM, BN, BK;
   tile_of(c.algo, &BM, &BN, &BK);
   ADVHIP_REQUIRE(instantiated(c.algo), "conv3d: algo %d is not instantiated in this library", c.algo);
@@ -1684,7 +1868,8 @@ static int pool_out(int n, int k, int s) { return n >= k ? (n - k) / s + 1 : 0; 
 static int fill_pool_args(ConvArgs& a, const advhip_conv3d_desc* d, const Geometry& g, const float* x, int64_t x_batch_stride,
                           const float* w_packed, const int32_t* ktab, const float* scale, const float* shift, bool flat_hw) {
   a.x = x; a.w = w_packed; a.ktab = reinterpret_cast<const int4*>(ktab);
-  a.scale = scale; a.shift = shift; a.res = nullptr; a.y = nullptr;
+  a.scale = scale; a.shift = shift; a.res = nullptr; a.y = nullptr; a.y2 = nullptr; a.dact = nullptr;
+  a.ln_u = nullptr; a.ln_mu = nullptr; a.ln_rs = nullptr;
   a.B = d->B; a.Cin = d->Cin; a.T = d->T; a.Cout = d->Cout;
   a.H = flat_hw ? 1 : d->H; a.W = flat_hw ? d->H * d->W : d->W;
   a.st = d->st; a.sh = d->sh; a.sw = d->sw; a.pt = d->pt; a.ph = d->ph; a.pw = d->pw;
@@ -1801,4 +1986,30 @@ extern "C" int advhip_conv3d_bn_act_maxpool211_f32(const advhip_conv3d_desc* d, 
   const dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
   hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, false, 2, EPI_TPOOL>), grid, dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("conv3d+pool211");
+}
+
+
+// ---- "NT" product of two k-contiguous operands (weight gradients of the GEMM-shaped MGFN layers) --------------------------
+extern "C" int advhip_gemm_nt_f32(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda,
+                                  int64_t ldb, int64_t ldc, int32_t splits, int64_t slab_stride, void* stream) {
+  ADVHIP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "gemm_nt: bad arguments");
+  ADVHIP_REQUIRE(K % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0,
+                 "gemm_nt: K=%d must be a multiple of 16 and the operands 16-byte aligned with row pitches that are multiples of 4", K);
+  ADVHIP_REQUIRE(lda >= K && ldb >= K && ldc >= N, "gemm_nt: row pitch smaller than a row");
+  const long long a_bytes = ((long long)(M - 1) * lda + K) * 4, b_bytes = ((long long)(N - 1) * ldb + K) * 4;
+  ADVHIP_REQUIRE(a_bytes < 0xF0000000ll && b_bytes < 0xF0000000ll, "gemm_nt: operand above 3.75 GiB");
+  ADVHIP_REQUIRE(splits >= 1 && splits <= K / 16 && (splits == 1 || slab_stride >= (long long)(M - 1) * ldc + N), "gemm_nt: bad split count %d", splits);
+  GemmKKArgs g;
+  g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
+  g.lda = (int)lda; g.ldb = (int)ldb; g.ldc = (int)ldc;
+  g.a_bytes = (unsigned)a_bytes; g.b_bytes = (unsigned)b_bytes;
+  g.splits = splits; g.slab = slab_stride;
+  const bool big = (long long)((M + 127) / 128) * ((N + 63) / 64) * splits >= 1536;
+  g.tiles_m = big ? (M + 127) / 128 : (M + 63) / 64;
+  g.tiles_n = (N + 63) / 64;
+  const long long blocks = (long long)g.tiles_m * g.tiles_n * splits;
+  ADVHIP_REQUIRE(blocks < (1ll << 31), "gemm_nt: too many tiles");
+  if (big) hipLaunchKernelGGL((gemm_kk_dma_kernel<128, 64>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL((gemm_kk_dma_kernel<64, 64>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+  return check_launch("gemm_nt");
 }

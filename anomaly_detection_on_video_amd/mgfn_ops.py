@@ -1,0 +1,193 @@
+"""GEMM-shaped layers of the MGFN scorer on the hand-written fp32-MFMA kernels, forward and backward.
+
+Activations are (C, B, T) -- channels outermost, as in models/mgfn/modeling_mgfn.py -- so a 1x1 Conv1d is the GEMM
+Y[o, n] = W[o, c] X[c, n] over n = (b, t), and that GEMM is a 1x1x1 convolution of the LDS-DMA implicit-GEMM kernel on a
+(1, C, 1, 1, B*T) tensor (a k = 3 Conv1d: kernel (1,1,3) on (1, C, 1, B, T), im2col-free), with bias, GELU, residual, the
+channel-LayerNorm fold and the GELU backward in its epilogue (include/advhip.h: advhip_conv3d_bn_act_ex_f32).  Per layer:
+
+    forward   Y  = act(W X + b) (+ R)            conv kernel, weights re-packed to [c][o] when the parameter changed
+    backward  dX = W^T dY (* GELU'(z))           conv kernel on the parameter's own [o][c] layout (no packing)
+              dW = dY X^T                        advhip_gemm_nt_f32 (both operands position-contiguous: LDS-DMA row copies)
+              db = row sums of dY                torch reduction
+
+Replaces the Conv1d calls of MGFNFeedForward / FocusAttention / FocusBlock / MGFNIntermediate
+(/root/reference/src/models/mgfn/modeling_mgfn.py:49-64, 150-216).  CUDA tensors only; layers that do not fit the
+kernels' shapes (fewer than 128 channels, Cout % 64 != 0, Cin % 32 != 0) stay on the torch ops of modeling_mgfn.py.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib, ops
+from ._lib import ConvDesc, ConvEpilogue, check, ptr, stream
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+ALGO = _lib.ALGO_DMA2_BASE + _lib.ALGO_IGEMM_128x64  # 128 x 64 x 16 tiles, 2-deep LDS-DMA ring: 139-146 TFLOP/s on these GEMMs
+
+_KTABS: Dict[Tuple, torch.Tensor] = {}
+_CONST: Dict[Tuple, torch.Tensor] = {}
+
+
+def eligible(cin: int, cout: int, x: torch.Tensor) -> bool:
+    return x.is_cuda and x.dtype == torch.float32 and min(cin, cout) >= 128 and cout % 64 == 0 and cin % 32 == 0
+
+
+def _desc(cin: int, cout: int, k: int, b: int, t: int, act: int) -> ConvDesc:
+    # (1, C, 1, b, t) tensor, kernel (1, 1, k), padding (0, 0, k // 2): for k = 1 the caller folds (b, t) into one row
+    return ConvDesc(1, cin, 1, b, t, cout, 1, 1, k, 1, 1, 1, 0, 0, k // 2, act, ALGO, 1)
+
+
+def _ktab(d: ConvDesc, dev) -> torch.Tensor:
+    key = (d.Cin, d.H, d.W, d.kw, dev)
+    tab = _KTABS.get(key)
+    if tab is None:
+        lib = _lib.load()
+        rows = lib.advhip_conv3d_packed_rows(C.byref(d))
+        tab = torch.empty((rows * 6,), device=dev, dtype=torch.int32)
+        check(lib.advhip_conv3d_build_ktab(C.byref(d), ptr(tab), stream()), "build_ktab")
+        _KTABS[key] = tab
+    return tab
+
+
+def _const(n: int, value: float, dev) -> torch.Tensor:
+    key = (n, value, dev)
+    if key not in _CONST:
+        _CONST[key] = torch.full((n,), value, device=dev, dtype=torch.float32)
+    return _CONST[key]
+
+
+def pack_kc(w: torch.Tensor) -> torch.Tensor:
+    """(Cout, Cin, k) Conv1d weights -> the kernels' [Cin*k (padded to 32)][Cout] operand."""
+    cout, cin, k = w.shape
+    d = _desc(cin, cout, k, 1, 1, 0)
+    lib = _lib.load()
+    wp = torch.empty((lib.advhip_conv3d_packed_rows(C.byref(d)), cout), device=w.device, dtype=torch.float32)
+    check(lib.advhip_conv3d_pack_weight_f32(C.byref(d), ptr(w.contiguous()), ptr(wp), stream()), "pack_weight")
+    return wp
+
+
+def conv_cn(x: torch.Tensor, w_packed: torch.Tensor, cout: int, k: int = 1, shift: Optional[torch.Tensor] = None,
+            residual: Optional[torch.Tensor] = None, act: int = ACT_NONE, want_preact: bool = False,
+            dact_z: Optional[torch.Tensor] = None, ln: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None):
+    """act(conv1d_k(x) + shift) (+ residual) for x (Cin, B, T) contiguous -> (Cout, B, T) [, pre-activation].  One launch."""
+    cin, b, t = x.shape
+    if not x.is_contiguous():
+        raise _lib.HipExtensionError("conv_cn needs a contiguous (C, B, T) activation")
+    d = _desc(cin, cout, k, 1 if k == 1 else b, b * t if k == 1 else t, act)
+    dev = x.device
+    y = torch.empty((cout, b, t), device=dev, dtype=torch.float32)
+    z = torch.empty_like(y) if want_preact else None
+    ep = ConvEpilogue(ptr(z), ptr(dact_z), ptr(ln[0]) if ln else None, ptr(ln[1]) if ln else None, ptr(ln[2]) if ln else None)
+    for tns in (residual, dact_z):
+        if tns is not None and (tuple(tns.shape) != (cout, b, t) or not tns.is_contiguous()):
+            raise ValueError("conv_cn: residual / dact_z must be contiguous (Cout, B, T)")
+    check(_lib.load().advhip_conv3d_bn_act_ex_f32(C.byref(d), ptr(x), 0, ptr(w_packed), ptr(_ktab(d, dev)), ptr(_const(cout, 1.0, dev)),
+                                                  ptr(shift if shift is not None else _const(cout, 0.0, dev)), ptr(residual), ptr(y), 0,
+                                                  C.byref(ep), None, 0, stream()), "conv_cn")
+    return (y, z) if want_preact else y
+
+
+def chan_stats(x: torch.Tensor, eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(mean, 1 / (std_biased + eps)) over the channels of a contiguous (C, B, T) activation, per position."""
+    c = x.shape[0]
+    n = x.numel() // c
+    mu = torch.empty((n,), device=x.device, dtype=torch.float32)
+    rs = torch.empty_like(mu)
+    check(_lib.load().advhip_chan_stats_f32(ptr(x), ptr(mu), ptr(rs), c, n, C.c_float(eps), stream()), "chan_stats")
+    return mu, rs
+
+
+def _unfold3(x: torch.Tensor) -> torch.Tensor:
+    """(C, B, T) -> ((c, tap) = 3C, B*T): the rows a k = 3, padding 1 conv contracts with, tap-minor like the weights."""
+    c, b, t = x.shape
+    xp = torch.nn.functional.pad(x, (1, 1))
+    return torch.stack([xp[:, :, j : j + t] for j in range(3)], dim=1).reshape(3 * c, b * t)
+
+
+class _LinearCN(torch.autograd.Function):
+    """y = conv1d_k(x; W) + b (+ residual), k in {1, 3}, no activation."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual):
+        cout, cin, k = weight.shape
+        y = conv_cn(x, pack_kc(weight.detach()), cout, k, shift=bias.detach() if bias is not None else None,
+                    residual=residual.detach().contiguous() if residual is not None else None)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        cout, cin, k = weight.shape
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if k == 1:  # dX = W^T dY: the parameter's own (o, c) layout IS the kernels' [K = o][Cout = c] operand
+                dx = conv_cn(dy, weight.detach().view(cout, cin), cin, 1)
+            else:       # transposed conv: W'[c][o][j] = W[o][c][k-1-j]
+                dx = conv_cn(dy, pack_kc(weight.detach().flip(2).transpose(0, 1)), cin, k)
+        if ctx.needs_input_grad[1]:
+            dy2 = dy.view(cout, -1)
+            if k == 1:
+                dw = ops.gemm_nt(dy2, x.detach().view(cin, -1)).view(cout, cin, 1)
+            else:
+                dw = ops.gemm_nt(dy2, _unfold3(x.detach())).view(cout, cin, 3)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(dim=(1, 2))
+        return dx, dw, db, (dy if ctx.has_res and ctx.needs_input_grad[3] else None)
+
+
+class _FFNCN(torch.autograd.Function):
+    """y = W2 GELU(W1 xh + b1) + b2 + x_res: MGFNFeedForward's convs (modeling_mgfn.py:53-64) and the block's residual add
+    as two launches forward (GELU and its pre-activation in the first one's epilogue, bias + residual in the second's) and
+    two + two backward (GELU' in the epilogue of the GEMM that produces dL/dh)."""
+
+    @staticmethod
+    def forward(ctx, xh, x_res, w1, b1, w2, b2):
+        hid, dim = w1.shape[0], w1.shape[1]
+        need_z = any(ctx.needs_input_grad)
+        out = conv_cn(xh, pack_kc(w1.detach()), hid, 1, shift=b1.detach(), act=ACT_GELU, want_preact=need_z)
+        h, z = out if need_z else (out, None)
+        y = conv_cn(h, pack_kc(w2.detach()), dim, 1, shift=b2.detach(), residual=x_res.detach().contiguous())
+        if need_z:
+            ctx.save_for_backward(xh, z, h, w1, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xh, z, h, w1, w2 = ctx.saved_tensors
+        hid, dim = w1.shape[0], w1.shape[1]
+        dy = dy.contiguous()
+        dz = conv_cn(dy, w2.detach().view(dim, hid), hid, 1, dact_z=z)          # (W2^T dY) * GELU'(z)
+        dxh = conv_cn(dz, w1.detach().view(hid, dim), dim, 1) if ctx.needs_input_grad[0] else None
+        dw2 = ops.gemm_nt(dy.view(dim, -1), h.view(hid, -1)).view(dim, hid, 1) if ctx.needs_input_grad[4] else None
+        dw1 = ops.gemm_nt(dz.view(hid, -1), xh.detach().view(dim, -1)).view(hid, dim, 1) if ctx.needs_input_grad[2] else None
+        db2 = dy.sum(dim=(1, 2)) if ctx.needs_input_grad[5] else None
+        db1 = dz.sum(dim=(1, 2)) if ctx.needs_input_grad[3] else None
+        return dxh, (dy if ctx.needs_input_grad[1] else None), dw1, db1, dw2, db2
+
+
+def linear_cn(x: torch.Tensor, conv: torch.nn.Conv1d, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    return _LinearCN.apply(x.contiguous(), conv.weight, conv.bias, residual)
+
+
+def ffn_cn(xh: torch.Tensor, x_res: torch.Tensor, in_conv: torch.nn.Conv1d, out_conv: torch.nn.Conv1d) -> torch.Tensor:
+    return _FFNCN.apply(xh.contiguous(), x_res, in_conv.weight, in_conv.bias, out_conv.weight, out_conv.bias)
+
+
+@torch.no_grad()
+def ffn_cn_folded_ln(x: torch.Tensor, norm, in_conv: torch.nn.Conv1d, out_conv: torch.nn.Conv1d) -> torch.Tensor:
+    """Inference form of `ffn(x) + x` with the channel LayerNorm folded into the first GEMM: W1.LN(x) = (W1.diag(g)) x_raw
+    * rs - rowsum(W1.diag(g)) * mu * rs + W1.b, statistics per position from one pass over x (advhip_chan_stats_f32)."""
+    x = x.contiguous()
+    hid, dim = in_conv.weight.shape[0], in_conv.weight.shape[1]
+    w1 = in_conv.weight.view(hid, dim)
+    wg = w1 * norm.g.view(1, dim)
+    mu, rs = chan_stats(x, norm.eps)
+    shift = in_conv.bias + w1 @ norm.b.view(dim)
+    h = conv_cn(x, pack_kc(wg.view(hid, dim, 1)), hid, 1, shift=shift, act=ACT_GELU, ln=(wg.sum(1).contiguous(), mu, rs))
+    return conv_cn(h, pack_kc(out_conv.weight), dim, 1, shift=out_conv.bias, residual=x)

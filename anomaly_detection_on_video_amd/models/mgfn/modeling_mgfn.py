@@ -22,7 +22,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ... import mil_ops
+from ... import mgfn_ops, mil_ops
 from .configuration_mgfn import MGFNConfig
 
 try:
@@ -70,9 +70,25 @@ else:  # pragma: no cover
 # (rocBLAS fp32 MFMA, forward and backward), with no layout copies between layers.  The nn.Conv1d /
 # nn.BatchNorm1d children remain the parameter holders (reference state-dict keys); their own
 # forward is not used.
+#
+# Layers with >= 128 channels on both sides (stages 1 and 2: 97 % of the scorer's MACs) do not go to rocBLAS but to the
+# hand-written fp32-MFMA kernels through `mgfn_ops` (forward AND backward: the LDS-DMA conv kernel as a GEMM with bias /
+# GELU / residual / LayerNorm-fold / GELU-backward epilogues, advhip_gemm_nt_f32 for the weight gradients); the stage-0
+# layers (64 channels), the 2049-channel amplifier and the attention einsums stay on the torch ops below.
 # ------------------------------------------------------------------------------------------------
-def _pointwise(conv: nn.Conv1d, x: torch.Tensor) -> torch.Tensor:
-    """1x1 Conv1d on a (C, B, T) tensor."""
+def _hip(conv: nn.Conv1d, x: torch.Tensor) -> bool:
+    return conv.weight.shape[2] in (1, 3) and mgfn_ops.eligible(conv.weight.shape[1], conv.weight.shape[0], x)
+
+
+def _pointwise(conv: nn.Conv1d, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """1x1 Conv1d on a (C, B, T) tensor (+ residual)."""
+    if _hip(conv, x):
+        return mgfn_ops.linear_cn(x, conv, residual)
+    y = _pointwise_torch(conv, x)
+    return y if residual is None else y + residual
+
+
+def _pointwise_torch(conv: nn.Conv1d, x: torch.Tensor) -> torch.Tensor:
     c, b, t = x.shape
     y = torch.matmul(conv.weight[:, :, 0], x.reshape(c, b * t))
     if conv.bias is not None:
@@ -80,11 +96,17 @@ def _pointwise(conv: nn.Conv1d, x: torch.Tensor) -> torch.Tensor:
     return y.view(-1, b, t)
 
 
-def _conv_k(conv: nn.Conv1d, x: torch.Tensor) -> torch.Tensor:
-    """Conv1d with odd kernel k, padding k//2, stride 1 on a (C, B, T) tensor: GEMM over (tap, channel)."""
+def _conv_k(conv: nn.Conv1d, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Conv1d with odd kernel k, padding k//2, stride 1 on a (C, B, T) tensor (+ residual): GEMM over (tap, channel)."""
     o, c, k = conv.weight.shape
-    if k == 1:
-        return _pointwise(conv, x)
+    if k == 1 or _hip(conv, x):
+        return _pointwise(conv, x, residual)
+    y = _conv_k_torch(conv, x)
+    return y if residual is None else y + residual
+
+
+def _conv_k_torch(conv: nn.Conv1d, x: torch.Tensor) -> torch.Tensor:
+    o, c, k = conv.weight.shape
     _, b, t = x.shape
     xp = F.pad(x, (k // 2, k // 2))
     xu = torch.cat([xp[:, :, j : j + t] for j in range(k)], dim=0)  # ((tap, c), B, T)
@@ -118,8 +140,17 @@ class MGFNFeedForward(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.out_conv = nn.Conv1d(dim * repe, dim, 1)
 
-    def forward(self, x):
-        return _pointwise(self.out_conv, self.dropout(self.gelu(_pointwise(self.in_conv, self.layer_norm(x)))))
+    def forward(self, x, residual: Optional[torch.Tensor] = None):
+        """ffn(x) (+ residual).  On the HIP path the two GEMMs carry bias, GELU (+ its backward) and the residual in their
+        epilogues; without autograd the LayerNorm is folded into the first one as well."""
+        if (_hip(self.in_conv, x) and _hip(self.out_conv, x) and residual is not None
+                and not (self.training and self.dropout.p > 0)):
+            if not torch.is_grad_enabled():
+                if residual is x:
+                    return mgfn_ops.ffn_cn_folded_ln(x, self.layer_norm, self.in_conv, self.out_conv)
+            return mgfn_ops.ffn_cn(self.layer_norm(x), residual, self.in_conv, self.out_conv)
+        y = _pointwise(self.out_conv, self.dropout(self.gelu(_pointwise(self.in_conv, self.layer_norm(x)))))
+        return y if residual is None else y + residual
 
 
 class MGFNFeatureAmplifier(nn.Module):
@@ -150,13 +181,13 @@ class GlanceAttention(nn.Module):
         self.to_qkv = nn.Conv1d(dim, dim_head * heads * 3, 1, bias=False)
         self.to_out = nn.Conv1d(dim_head * heads, dim, 1)
 
-    def forward(self, x):  # (C, B, T)
+    def forward(self, x, residual: Optional[torch.Tensor] = None):  # (C, B, T)
         _, b, n = x.shape
         qkv = _pointwise(self.to_qkv, self.norm(x)).view(3, self.heads, self.dim_head, b, n)
         q, k, v = (t.permute(2, 0, 1, 3) for t in qkv.unbind(0))  # (b, h, d, n)
         sim = torch.matmul((q * self.scale).transpose(-1, -2), k)  # (b, h, i, j)
         out = torch.matmul(v, sim.softmax(dim=-1).transpose(-1, -2))  # (b, h, d, i)
-        return _pointwise(self.to_out, out.permute(1, 2, 0, 3).reshape(self.heads * self.dim_head, b, n))
+        return _pointwise(self.to_out, out.permute(1, 2, 0, 3).reshape(self.heads * self.dim_head, b, n), residual)
 
 
 class FocusAttention(nn.Module):
@@ -187,7 +218,7 @@ class FocusAttention(nn.Module):
         scale = bn.weight * torch.rsqrt(var + bn.eps)
         return x * scale[:, None, None] + (bn.bias - mean * scale)[:, None, None]
 
-    def forward(self, x):  # (C, B, T)
+    def forward(self, x, residual: Optional[torch.Tensor] = None):  # (C, B, T)
         _, b, n = x.shape
         v = _pointwise(self.to_v, self._batch_norm(x))
         inner = v.shape[0]
@@ -199,14 +230,16 @@ class FocusAttention(nn.Module):
         out = self.rel_pos.bias.view(1, h, 1, 1)
         for j in range(k):
             out = out + w[:, j].view(1, h, 1, 1) * vp[..., j : j + n]
-        return _pointwise(self.to_out, out.reshape(inner, b, n))
+        return _pointwise(self.to_out, out.reshape(inner, b, n), residual)
 
 
 class _Block(nn.Module):
     def forward(self, x):
-        x = _conv_k(self.scc, x) + x
-        x = self.attention(x) + x
-        return self.ffn(x) + x
+        # x = scc(x) + x;  x = attention(x) + x;  x = ffn(x) + x  (modeling_mgfn.py:143-147, 201-205): the residual adds ride
+        # in the epilogue of the GEMM that ends each branch
+        x = _conv_k(self.scc, x, residual=x)
+        x = self.attention(x, residual=x)
+        return self.ffn(x, residual=x)
 
 
 class GlanceBlock(_Block):

@@ -356,3 +356,20 @@ def softmax_rows(x: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor
     n = x.shape[-1]
     check(_lib.load().advhip_softmax_rows_f32(ptr(x), ptr(y), x.numel() // n, n, C.c_float(scale), stream()), "softmax_rows")
     return y
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, splits: int = 0) -> torch.Tensor:
+    """a (M, K) @ b (N, K)^T -> (M, N) for two k-contiguous operands (row pitch = stride(0)); K % 16 == 0.  The weight
+    gradient of a GEMM-shaped layer with (channel, position) activations (include/advhip.h: advhip_gemm_nt_f32).
+    `splits`: K slices (0 = enough to fill the chip); the slices are summed here."""
+    require_gpu(a, b, contiguous=False)
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1] or a.stride(1) != 1 or b.stride(1) != 1:
+        raise ValueError(f"gemm_nt: need (M,K) and (N,K) with unit inner stride, got {tuple(a.shape)} {a.stride()} / {tuple(b.shape)} {b.stride()}")
+    M, K = a.shape
+    N = b.shape[0]
+    if splits <= 0:
+        tiles = -(-M // 64) * -(-N // 64)
+        splits = max(1, min(8, 1024 // max(tiles, 1), K // 256))
+    out = torch.empty((splits, M, N), device=a.device, dtype=torch.float32)
+    check(_lib.load().advhip_gemm_nt_f32(ptr(a), ptr(b), ptr(out), M, N, K, a.stride(0), b.stride(0), N, splits, M * N, stream()), "gemm_nt")
+    return out[0] if splits == 1 else out.sum(0)

@@ -62,7 +62,7 @@ typedef struct advhip_conv3d_desc {
   int32_t Cout, kt, kh, kw;   /* weight (Cout, Cin, kt, kh, kw), bias-free */
   int32_t st, sh, sw;         /* stride */
   int32_t pt, ph, pw;         /* zero padding */
-  int32_t relu;               /* apply max(0,.) last */
+  int32_t relu;               /* activation applied last: 0 none, 1 ReLU max(0,.), 2 GELU (erf form, nn.GELU()) */
   int32_t algo;               /* ADVHIP_ALGO_* */
   int32_t splits;             /* split-K factor: 0 = heuristic, 1 = none, n = n K-slices + reduce pass */
 } advhip_conv3d_desc;
@@ -124,6 +124,32 @@ int advhip_conv3d_bn_act_strided_f32(const advhip_conv3d_desc* d, const float* x
                                      const float* w_packed, const int32_t* ktab, const float* scale, const float* shift,
                                      const float* residual, float* y, int64_t y_batch_stride, void* workspace,
                                      int64_t workspace_bytes, void* stream);
+
+/* The same with the two extra epilogue operands the MGFN scorer's GEMM-shaped layers need (a 1x1 Conv1d over a
+ * (C, B*T) activation is this conv on a (1, C, 1, 1, B*T) tensor; src/models/mgfn/modeling_mgfn.py:49-64, 150-205):
+ *   y_preact (nullable, y's shape / batch stride): receives the value BEFORE the activation -- z of h = GELU(z), kept for
+ *            the backward pass while y gets h (MGFNFeedForward in_conv -> GELU, :53-56);
+ *   dact_z   (nullable, y's shape, dense): the result is multiplied by GELU'(dact_z) -- the backward of that GELU fused into
+ *            the GEMM that produces dL/dh (dL/dz = (W_out^T . dL/dy) * GELU'(z)).
+ *   ln_u / ln_mu / ln_rs (nullable, together): the channel-LayerNorm fold for a 1x1x1 conv -- with w_packed holding
+ *            W.diag(g) and ln_u[n] its row sums, v = acc * ln_rs[m] - ln_u[n] * ln_mu[m] * ln_rs[m] turns the conv of the RAW
+ *            activation into W.LN(x) minus the W.b term (put W.b + bias in `shift`): MGFNLayerNorm (:36-46) never
+ *            materialises; ln_mu / ln_rs are per position m (advhip_chan_stats_f32). */
+typedef struct advhip_conv3d_epilogue {
+  float* y_preact;
+  const float* dact_z;
+  const float* ln_u;
+  const float* ln_mu;
+  const float* ln_rs;
+} advhip_conv3d_epilogue;
+int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const float* x, int64_t x_batch_stride, const float* w_packed,
+                                const int32_t* ktab, const float* scale, const float* shift, const float* residual, float* y,
+                                int64_t y_batch_stride, const advhip_conv3d_epilogue* ep, void* workspace,
+                                int64_t workspace_bytes, void* stream);
+
+/* mu[n] = mean over channels of x[c, n], rs[n] = 1 / (sqrt(biased variance over channels) + eps) for a (C, N) activation:
+ * the statistics of MGFNLayerNorm (modeling_mgfn.py:43-46: division by std + eps, not sqrt(var + eps)). */
+int advhip_chan_stats_f32(const float* x, float* mu, float* rs, int32_t C, int64_t N, float eps, void* stream);
 
 /* --- conv + max-pool fused (the two nn.MaxPool3d of I3Res50.forward_single, src/i3d.py:303-309) -------------------
  * Pooled extents of conv(d) followed by a floor-mode, padding-0 max-pool with window pk* and stride ps*. */
@@ -192,6 +218,13 @@ typedef struct advhip_gemm_desc {
   const float* residual;
 } advhip_gemm_desc;
 int advhip_bgemm_f32(const advhip_gemm_desc* d, const float* A, const float* B, float* C, void* stream);
+
+/* C[s][m][n] = sum over K slice s of A[m][k] * B[n][k]: both operands k-contiguous with row pitches lda / ldb (elements,
+ * multiples of 4; K a multiple of 16; 16-byte aligned bases).  The weight gradient dW[o][c] = sum_n dY[o][n] X[c][n] of
+ * the MGFN scorer's GEMM-shaped layers, whose activations are stored (channel, position): no transposed copies.  LDS-DMA
+ * row copies, fp32 MFMA.  splits > 1 cuts K into slices written to C + s * slab_stride (the caller sums them). */
+int advhip_gemm_nt_f32(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb,
+                       int64_t ldc, int32_t splits, int64_t slab_stride, void* stream);
 
 /* y[r, :] = softmax(x[r, :] * scale) over rows of n contiguous floats (F.softmax(theta_phi * dim_inner**-0.5, dim=-1),
  * src/i3d.py:174-175; the attention softmax of GlanceAttention, modeling_mgfn.py:115-120).  x == y allowed. */

@@ -240,3 +240,49 @@ def test_head_refuses_cpu_tensors():
     m = MGFNForVideoAnomalyDetection(MGFNConfig()).eval()
     with pytest.raises(_lib.HipExtensionError):
         m(video=mgfn_inputs(1, 8, 0))
+
+
+def test_hip_gemm_path_matches_torch_path_forward_and_every_gradient(model_and_sd, monkeypatch):
+    """Stages 1-2 of the body run on the hand-written kernels (mgfn_ops: conv-kernel GEMMs with fused epilogues forward,
+    W^T.dY with GELU' and advhip_gemm_nt_f32 backward).  Same model, same batch with that path switched off (every layer
+    on the torch / rocBLAS ops): scores, loss and the gradient of EVERY parameter must agree; so must the no-grad
+    inference form, where the channel LayerNorm is folded into the first FFN GEMM."""
+    from anomaly_detection_on_video_amd import mgfn_ops
+
+    model, sd = model_and_sd
+    video = mgfn_inputs(4, 32, 0).to(DEV)
+    nl, al = torch.zeros(2, device=DEV), torch.ones(2, device=DEV)
+    calls = {"n": 0}
+    real = mgfn_ops.conv_cn
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    def run(hip: bool, grad: bool):
+        _reset(model, sd)
+        model.train()
+        model.injected_keep = (torch.ones(2, 32, device=DEV), torch.ones(2, 32, device=DEV))
+        with monkeypatch.context() as mp:
+            if not hip:
+                mp.setattr(mgfn_ops, "eligible", lambda *a: False)
+            mp.setattr(mgfn_ops, "conv_cn", counting)
+            if grad:
+                o = model(video=video, abnormal_labels=al, normal_labels=nl)
+                o.loss.backward()
+                return o.scores.detach().clone(), o.loss.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+            model.eval()
+            with torch.no_grad():
+                return model(video=video).scores.clone(), None, None
+
+    s_h, l_h, g_h = run(True, True)
+    n_hip = calls["n"]
+    s_t, l_t, g_t = run(False, True)
+    assert n_hip >= 40 and calls["n"] == n_hip  # the HIP path really ran (and only when switched on)
+    assert rel_err(s_h.cpu(), s_t.cpu()) < 1e-5 and rel_err(l_h.cpu(), l_t.cpu()) < 1e-5
+    worst = max((rel_err(g_h[k].cpu(), g_t[k].cpu()), k) for k in g_h)
+    assert worst[0] < 2e-4, worst
+    e_h, _, _ = run(True, False)
+    e_t, _, _ = run(False, False)
+    assert rel_err(e_h.cpu(), e_t.cpu()) < 1e-5
+    model.injected_keep = None

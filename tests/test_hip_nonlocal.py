@@ -188,3 +188,18 @@ def test_i3d_8x8_r50_topology_vs_torch_restatement(monkeypatch):
         assert rel_err(y, ref) < 1e-4, shape
     with pytest.raises(ValueError):
         m(synth_input((1, 3, 4, 224, 224), 0).to(_dev()))  # T = 2 after the stage-1 pool: smaller than the head's (4,7,7) window
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(64, 64, 16, 1), (100, 70, 160, 1), (256, 192, 1024, 4), (1024, 128, 10240, 0), (130, 1024, 2048, 3), (1, 5, 32, 2)])
+def test_gemm_nt_vs_torch_fp64(M, N, K, splits):
+    """advhip_gemm_nt_f32 (both operands k-contiguous, LDS-DMA row copies): dW = dY . X^T shapes, ragged M / N, K slices,
+    operands that are row slices of wider matrices (row pitch > K)."""
+    from anomaly_detection_on_video_amd import ops
+
+    a = synth_tensor(f"nt.a{M}{K}", (M, K + 32), scale=1.0).to(_dev())[:, 16 : 16 + K]
+    b = synth_tensor(f"nt.b{N}{K}", (N, K), scale=1.0).to(_dev())
+    out = ops.gemm_nt(a, b, splits)
+    ref = a.double().cpu() @ b.double().cpu().t()
+    assert out.shape == (M, N)
+    assert rel_err(out.cpu(), ref) < 3e-6
+    assert torch.equal(out, ops.gemm_nt(a, b, splits))
