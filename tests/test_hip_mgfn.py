@@ -272,6 +272,7 @@ def test_hip_gemm_path_matches_torch_path_forward_and_every_gradient(model_and_s
                 o.loss.backward()
                 return o.scores.detach().clone(), o.loss.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
             model.eval()
+            model.injected_keep = None
             with torch.no_grad():
                 return model(video=video).scores.clone(), None, None
 

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Dev tool: N MGFN training steps (32,10,32,2049) for rocprofv3; prints wall ms per step."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from anomaly_detection_on_video_amd.models.mgfn import MGFNConfig, MGFNForVideoAnomalyDetection  # noqa: E402
+from anomaly_detection_on_video_amd.weights import synth_module_state_dict  # noqa: E402
+
+dev = "cuda:0"
+m = MGFNForVideoAnomalyDetection(MGFNConfig())
+m.load_state_dict(synth_module_state_dict(m))
+m = m.to(dev).train()
+vb = torch.rand(32, 10, 32, 2049, device=dev)
+al, nl = torch.ones(16, device=dev), torch.zeros(16, device=dev)
+opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-4)
+
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    m(video=vb, abnormal_labels=al, normal_labels=nl).loss.backward()
+    opt.step()
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+t = time.perf_counter()
+for _ in range(n):
+    step()
+torch.cuda.synchronize()
+print(f"train step wall {(time.perf_counter() - t) / n * 1e3:.2f} ms")
