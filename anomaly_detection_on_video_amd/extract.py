@@ -136,6 +136,51 @@ def extract_video_frames(model, frames: torch.Tensor, frames_per_clip: int = FRA
     return np.squeeze(out)
 
 
+SEGMENT_FRAMES = 16 * 188  # 3008: extract_features.py:121
+
+
+def extract_long_video_frames(model, name: str, n_frames: int, read_frames: Callable[[int, int], torch.Tensor], outpath: str,
+                              seg_len: int = SEGMENT_FRAMES, **kw) -> np.ndarray:
+    """The reference's treatment of videos too large to hold in RAM (extract_features.py:116-148): the video is cut into
+    segments of `seg_len` frames (a multiple of 16, so only the last clip of the video is LoopPad-ed), each segment's
+    (n_clips, 10, 2048) features are cached as `<outpath>/<name>/<name>_<seg>.npy` and re-used on a later run, and the
+    segments are stacked.  `read_frames(start, stop)` returns the resized uint8 frames [start, stop) as (F, H, W, 3)."""
+    seg_folder = os.path.join(outpath, name)
+    os.makedirs(seg_folder, exist_ok=True)
+    segments = []
+    for seg in range(n_frames // seg_len + 1):
+        lo, hi = seg * seg_len, min((seg + 1) * seg_len, n_frames)
+        if lo >= hi:  # n_frames a multiple of seg_len: the reference's last segment is empty
+            continue
+        seg_path = os.path.join(seg_folder, f"{name}_{seg}.npy")
+        if os.path.exists(seg_path):
+            out = np.load(seg_path)
+        else:
+            out = extract_video_frames(model, read_frames(lo, hi), **kw)
+            np.save(seg_path, out)
+        segments.append(out.reshape(-1, NCROPS, 2048))
+    return np.vstack(segments)
+
+
+def extract_frames(sources: Iterable[Tuple[str, int, Callable[[int, int], torch.Tensor]]], model, outpath: str,
+                   long_video_frames: int = SEGMENT_FRAMES, seg_len: int = SEGMENT_FRAMES, **kw) -> Dict[str, str]:
+    """Per-video driver for frame sources (name, n_frames, read_frames): `<name>_i3d.npy` per video with the reference's
+    skip-if-exists rule (:106-110); videos longer than `long_video_frames` go through the per-segment cache."""
+    os.makedirs(outpath, exist_ok=True)
+    written = {}
+    for name, n_frames, read_frames in sources:
+        savepath = os.path.join(outpath, name + "_i3d.npy")
+        if os.path.exists(savepath):
+            continue
+        if n_frames > long_video_frames:
+            out = extract_long_video_frames(model, name, n_frames, read_frames, outpath, seg_len, **kw)
+        else:
+            out = extract_video_frames(model, read_frames(0, n_frames), **kw)
+        np.save(savepath, out)
+        written[name] = savepath
+    return written
+
+
 def extract(sources: Iterable[Tuple[str, Callable[[], torch.Tensor]]], model, outpath: str, **kw) -> Dict[str, str]:
     """Per-video driver with the reference's resume rule: skip a video whose `<name>_i3d.npy`
     exists (:106-110).  `sources` yields (name, loader) where loader() returns the clip tensor."""

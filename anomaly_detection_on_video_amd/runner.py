@@ -126,9 +126,41 @@ class LearningRateMonitor:
         return {"lr-Adam": optimizer.param_groups[0]["lr"]}
 
 
+def checkpoint_state(runner: "VideoAnomalyDetectionRunner", optimizer, epoch: int, global_step: int, metrics_: Dict[str, float]) -> Dict[str, Any]:
+    """A checkpoint in the key layout lightning.pytorch.ModelCheckpoint writes for the reference's LightningModule
+    (`self.model = model`, runner.py:21-24): `state_dict` with the `model.` prefix, `optimizer_states`, `epoch`,
+    `global_step`, `hyper_parameters` -- so files move between the reference and this trainer in both directions."""
+    return {
+        "epoch": epoch, "global_step": global_step,
+        "state_dict": {"model." + k: v for k, v in runner.model.state_dict().items()},
+        "optimizer_states": [optimizer.state_dict()], "lr_schedulers": [],
+        "hyper_parameters": {"optimizer": dict(runner.hparams.optimizer), "data": dict(runner.hparams.data)},
+        "metrics": dict(metrics_),
+    }
+
+
+def load_checkpoint(path: str, runner: "VideoAnomalyDetectionRunner", optimizer=None, strict: bool = True) -> Dict[str, Any]:
+    """Load a checkpoint written by this trainer, by the reference's Lightning trainer (`state_dict` keys prefixed
+    `model.`) or by this package's round-1 layout (`model` / `optimizer`) into the runner (and the optimizer)."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    if "state_dict" in ckpt:
+        sd = {(k[len("model."):] if k.startswith("model.") else k): v for k, v in ckpt["state_dict"].items()}
+        opt_state = (ckpt.get("optimizer_states") or [None])[0]
+    elif "model" in ckpt:
+        sd, opt_state = ckpt["model"], ckpt.get("optimizer")
+    else:  # a bare state dict
+        sd, opt_state = ckpt, None
+    runner.model.load_state_dict(sd, strict=strict)
+    if optimizer is not None and opt_state is not None:
+        optimizer.load_state_dict(opt_state)
+    runner.on_load_checkpoint(ckpt)
+    return ckpt
+
+
 class ModelCheckpoint:
-    """dirpath/last.pt every `every_n_epochs` epochs (+ top-k by `monitor`).  The reference's config
-    monitors `rec_auc` while the runner logs `valid/rec_auc`: both spellings work."""
+    """dirpath/last.ckpt every `every_n_epochs` epochs (+ top-k by `monitor`) in Lightning's checkpoint layout
+    (`checkpoint_state`).  The reference's config monitors `rec_auc` while the runner logs `valid/rec_auc`
+    (SURVEY.md S6): both spellings work."""
 
     def __init__(self, dirpath: str = "checkpoints", save_last: bool = True, save_top_k: int = 10, every_n_epochs: int = 10,
                  monitor: str = "rec_auc", mode: str = "max", verbose: bool = False):
@@ -140,14 +172,14 @@ class ModelCheckpoint:
         if (epoch + 1) % max(1, self.every_n_epochs):
             return
         os.makedirs(self.dirpath, exist_ok=True)
-        state = {"model": runner.model.state_dict(), "optimizer": optimizer.state_dict(), "epoch": epoch, "metrics": metrics_}
+        state = checkpoint_state(runner, optimizer, epoch, trainer.global_step, metrics_)
         runner.on_save_checkpoint(state)
         if self.save_last:
-            torch.save(state, os.path.join(self.dirpath, "last.pt"))
+            torch.save(state, os.path.join(self.dirpath, "last.ckpt"))
         val = metrics_.get(self.monitor, metrics_.get("valid/" + self.monitor))
         if val is None or self.save_top_k == 0:
             return
-        path = os.path.join(self.dirpath, f"epoch={epoch}-{self.monitor.replace('/', '_')}={val:.4f}.pt")
+        path = os.path.join(self.dirpath, f"epoch={epoch}-{self.monitor.replace('/', '_')}={val:.4f}.ckpt")
         torch.save(state, path)
         self.best.append((val if self.mode == "max" else -val, path))
         self.best.sort(reverse=True)
@@ -183,14 +215,37 @@ class Trainer:
         for lg in self.loggers:
             lg.log_metrics(m, self.global_step)
 
-    def fit(self, model: VideoAnomalyDetectionRunner) -> None:
+    @staticmethod
+    def _max_size_cycle(*loaders):
+        """Lightning's default way to combine the two train loaders (CombinedLoader mode "max_size_cycle"): as many
+        steps as the LONGER loader has, the shorter one restarts -- not zip(), which would stop at the shorter."""
+        n = max(len(ld) for ld in loaders)
+        its = [iter(ld) for ld in loaders]
+        for _ in range(n):
+            batch = []
+            for i, ld in enumerate(loaders):
+                try:
+                    batch.append(next(its[i]))
+                except StopIteration:
+                    its[i] = iter(ld)
+                    batch.append(next(its[i]))
+            yield tuple(batch)
+
+    def fit(self, model: VideoAnomalyDetectionRunner, ckpt_path: Optional[str] = None) -> None:
+        """`ckpt_path`: resume from a checkpoint (this trainer's or the reference's Lightning layout): weights,
+        optimizer state, epoch and global step."""
         runner = model.to(self.device)
         runner.setup("fit")
         (optimizer,) = runner.configure_optimizers()
-        for epoch in range(self.max_epochs):
+        first_epoch = 0
+        if ckpt_path:
+            ckpt = load_checkpoint(ckpt_path, runner, optimizer)
+            first_epoch = int(ckpt.get("epoch", -1)) + 1
+            self.global_step = int(ckpt.get("global_step", 0))
+        for epoch in range(first_epoch, self.max_epochs):
             runner.model.train()
             nloader, aloader = runner.train_dataloader()
-            for batch_idx, batch in enumerate(zip(nloader, aloader)):
+            for batch_idx, batch in enumerate(self._max_size_cycle(nloader, aloader)):
                 if 0 <= self.max_steps <= self.global_step:
                     break
                 batch = _to_device(batch, self.device)

@@ -31,7 +31,7 @@ def main(argv=None):
         loggers.append(instantiate(logger))
     callbacks = [instantiate(cb) for cb in (args.trainer.get("callbacks") or {}).values()]
     trainer = instantiate(args.trainer.cls, logger=loggers, callbacks=callbacks)
-    trainer.fit(model=runner)
+    trainer.fit(model=runner, ckpt_path=args.get("ckpt_path"))  # ckpt_path=<file>: resume (Lightning checkpoint layout)
     return trainer
 
 

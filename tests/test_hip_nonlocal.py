@@ -203,3 +203,38 @@ def test_gemm_nt_vs_torch_fp64(M, N, K, splits):
     assert out.shape == (M, N)
     assert rel_err(out.cpu(), ref) < 3e-6
     assert torch.equal(out, ops.gemm_nt(a, b, splits))
+
+
+def test_long_video_segment_cache_and_resume(tmp_path):
+    """extract_features.py:116-148: long videos are extracted per segment of frames, each segment cached as
+    <out>/<name>/<name>_<seg>.npy and re-used when the run is repeated; the stacked result equals the un-segmented one."""
+    from anomaly_detection_on_video_amd import extract
+    from anomaly_detection_on_video_amd.i3d import I3Res50
+
+    m = I3Res50()
+    m.load_state_dict(synth_i3d_state_dict())
+    m = m.eval().to(_dev())
+    frames = torch.from_numpy(np.random.default_rng(11).integers(0, 256, (72, 70, 80, 3), dtype=np.uint8))
+    reads = []
+
+    def read(lo, hi):
+        reads.append((lo, hi))
+        return frames[lo:hi]
+
+    out = str(tmp_path / "feat")
+    whole = extract.extract_video_frames(m, frames, crop=64)
+    written = extract.extract_frames([("vid", 72, read)], m, out, long_video_frames=32, seg_len=32, crop=64)
+    got = np.load(written["vid"])
+    assert got.shape == whole.shape == (5, 10, 2048) and rel_err(got, whole) < 1e-5
+    assert reads == [(0, 32), (32, 64), (64, 72)]
+    assert sorted(os.listdir(os.path.join(out, "vid"))) == ["vid_0.npy", "vid_1.npy", "vid_2.npy"]
+    # resume: the final file is gone, segment 1 comes from its cache (made recognisable), nothing is read again for it
+    os.remove(written["vid"])
+    os.remove(os.path.join(out, "vid", "vid_2.npy"))
+    seg1 = np.load(os.path.join(out, "vid", "vid_1.npy"))
+    np.save(os.path.join(out, "vid", "vid_1.npy"), seg1 + 1000.0)
+    reads.clear()
+    again = np.load(extract.extract_frames([("vid", 72, read)], m, out, long_video_frames=32, seg_len=32, crop=64)["vid"])
+    assert reads == [(64, 72)]
+    assert np.array_equal(again[2:4], seg1 + 1000.0) and rel_err(again[4:], whole[4:]) < 1e-5
+    assert extract.extract_frames([("vid", 72, read)], m, out, long_video_frames=32, seg_len=32, crop=64) == {}  # skip-if-exists

@@ -76,11 +76,31 @@ def test_run_py_trains_on_synthetic_corpus(tmp_path):
     assert len(steps) == 4 and len(vals) == 2  # 4 videos per class / batch 2 = 2 steps x 2 epochs
     assert all(np.isfinite(h["train_loss"]) for h in steps)
     assert all(0.0 <= h["valid/rec_auc"] <= 1.0 and 0.0 <= h["valid/pr_auc"] <= 1.0 for h in vals)
-    assert os.path.exists(os.path.join(ckpt, "last.pt"))
-    state = torch.load(os.path.join(ckpt, "last.pt"), map_location="cpu")
-    assert state["epoch"] == 1 and "fc.weight" in state["model"]
+    assert os.path.exists(os.path.join(ckpt, "last.ckpt"))
+    state = torch.load(os.path.join(ckpt, "last.ckpt"), map_location="cpu", weights_only=False)
+    # Lightning's checkpoint layout (the reference's LightningModule holds the net as `self.model`, runner.py:21-24)
+    assert state["epoch"] == 1 and state["global_step"] == 4 and "model.fc.weight" in state["state_dict"]
+    assert len(state["optimizer_states"]) == 1 and "optimizer" in state["hyper_parameters"]
     lines = [json.loads(l) for l in open(logp)]
     assert any("lr-Adam" in l for l in lines) and any("valid/pr_auc" in l for l in lines)
+    # resume: one more epoch from last.ckpt continues the step count and starts from the saved weights
+    trainer2 = run.main([
+        "data=synthetic", f"data.local_path={data_dir}", "data.batch_size=2", "trainer.cls.max_epochs=3",
+        f"trainer.callbacks.model_checkpoint.dirpath={ckpt}", "trainer.callbacks.model_checkpoint.every_n_epochs=1",
+        f"trainer.logger.jsonl.path={logp}", f"ckpt_path={os.path.join(ckpt, 'last.ckpt')}",
+    ])
+    steps2 = [h for h in trainer2.history if "train_loss" in h]
+    assert len(steps2) == 2 and steps2[0]["step"] == 5 and steps2[-1]["epoch"] == 2
+    # a reference-style checkpoint (bare Lightning keys) and the round-1 layout both load
+    from anomaly_detection_on_video_amd.models.mgfn import MGFNConfig, MGFNForVideoAnomalyDetection
+    from anomaly_detection_on_video_amd.runner import VideoAnomalyDetectionRunner, load_checkpoint
+
+    r = VideoAnomalyDetectionRunner(MGFNForVideoAnomalyDetection(MGFNConfig()), {"learning_rate": 1e-3, "weight_decay": 5e-4}, {"frames_per_clip": 16})
+    load_checkpoint(os.path.join(ckpt, "last.ckpt"), r)
+    assert torch.equal(r.model.fc.weight, state["state_dict"]["model.fc.weight"])
+    old = str(tmp_path / "old.pt")
+    torch.save({"model": {k[len("model."):]: v for k, v in state["state_dict"].items()}, "optimizer": state["optimizer_states"][0], "epoch": 0}, old)
+    load_checkpoint(old, r)
 
 
 def test_extract_driver_layout_resume_and_segment(tmp_path):
@@ -252,7 +272,8 @@ def test_end_to_end_extract_segment_train_auc(tmp_path):
     assert len(vals) == 3
     gpu_auc = vals[-1]["valid/rec_auc"]
     # oracle recomputation from the trained weights
-    state = torch.load(tmp_path / "ckpt" / "last.pt", map_location="cpu")["model"]
+    state = torch.load(tmp_path / "ckpt" / "last.ckpt", map_location="cpu", weights_only=False)["state_dict"]
+    state = {k[len("model."):]: v for k, v in state.items()}
     ds = build_feature_dataset("test", local_path=str(root), filename="test.zip", dynamic_load=False)
     preds, labels = [], []
     for i in range(len(ds)):

@@ -22,7 +22,7 @@ def load(pattern):
 def family(name):
     if "conv3d_igemm" in name or "splitk_reduce" in name:
         return "conv"
-    if "maxpool" in name or "avgpool" in name:
+    if "maxpool" in name or "avgpool" in name or "stem_pool_merge" in name:
         return "pool"
     if "advhip::" in name:
         return "advhip-other"

@@ -43,7 +43,13 @@ def layers(B=32):
         y = B * cout * to * ho * wo * 4
         wt = cout * cin * k[0] * k[1] * k[2] * 4
         macs = B * cout * to * ho * wo * cin * k[0] * k[1] * k[2]
-        res.append(dict(name=name, read=x + wt + (y if resid else 0), write=y, macs=macs))
+        wbytes = y
+        if name == "conv1":  # fused with maxpool1: writes the per-brick partial maxima (27 per brick and channel), not the activation
+            tp, hp, wp = to // 2, (ho - 3) // 2 + 1, (wo - 3) // 2 + 1
+            wbytes = B * tp * ((2 * hp + 1 + 3) // 4) * ((2 * wp + 1 + 15) // 16) * cout * 27 * 4
+        if name == "layer1.2.conv3":  # fused with maxpool2: writes the temporally pooled output
+            wbytes = y // 2
+        res.append(dict(name=name, read=x + wt + (y if resid else 0), write=wbytes, macs=macs))
     return res
 
 
