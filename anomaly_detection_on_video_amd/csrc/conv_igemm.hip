@@ -232,62 +232,56 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[B
     }
     return;
   }
-  // Generic path (THWo not a multiple of 4: rows of consecutive m may straddle a sample): direct
-  // per-lane stores of VW consecutive m.
-  const int m_lane = m0 + wm * Cfg::WM + FM * 4 * lg;  // first of FM*4 consecutive m
-  const int n_lane = n0 + b_col;
-  auto emit = [&](auto vw_tag) {
-    constexpr int VW = decltype(vw_tag)::value;  // divides FM and THWo
+  // Unaligned path (THWo not a multiple of 4 -- e.g. 2 x 7 x 7 = 98 positions per sample in layer 4 -- or pointers / strides that
+  // are not 16-byte aligned): the same LDS transposition, but the read phase gives every lane ONE position, so a
+  // wave-instruction stores (and reads the residual of) 64 consecutive m of a channel as whole dwords: coalesced 256-byte
+  // runs instead of 8-byte pieces scattered over 16 channels (which cost 3x the bytes at HBM: profiles/r02_*_traffic_by_layer.md).
+  {
+    float* st = smem + wave * (16 * Cfg::ST_STRIDE);
+    constexpr int RPI = 64 / Cfg::WM;      // channel rows per read instruction (1 or 2)
+    const int rrow = lane / Cfg::WM, rcol = lane % Cfg::WM;
+    const int mm = m0 + wm * Cfg::WM + rcol;
+    const bool mok = mm < a.M;
+    int bb = 0, pp = 0;
+    if (mok) { bb = (int)a.dTHWo.div((unsigned)mm); pp = mm - bb * a.THWo; }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int jn = 0; jn < FN; ++jn) {
 #pragma unroll
-      for (int v0 = 0; v0 < FM; v0 += VW) {
-        const int mm = m_lane + FM * r + v0;
-        if (mm >= a.M) continue;
-        const int bb = mm / a.THWo;
-        const int pp = mm - bb * a.THWo;
-#pragma unroll
-        for (int jn = 0; jn < FN; ++jn) {
-          const int n = n_lane + jn;
-          const size_t o = (size_t)(bb * a.Cout + n) * a.THWo + pp;
-          const size_t oy = fused ? (size_t)bb * a.y_bstride + (size_t)n * a.THWo + pp : o;
-          float vals[VW];
-#pragma unroll
-          for (int e = 0; e < VW; ++e) vals[e] = acc[v0 + e][jn][r];
-          if (fused) {
-            const float sc = a.scale[n], sf = a.shift[n];
-            if (a.ln_u) {
-              const float u = a.ln_u[n];
-#pragma unroll
-              for (int e = 0; e < VW; ++e) vals[e] = vals[e] * a.ln_rs[mm + e] - u * (a.ln_mu[mm + e] * a.ln_rs[mm + e]);
-            }
-#pragma unroll
-            for (int e = 0; e < VW; ++e) vals[e] = vals[e] * sc + sf;
-            if (a.res) {
-              float rv[VW];
-              vec_load<VW>(a.res + o, rv);
-#pragma unroll
-              for (int e = 0; e < VW; ++e) vals[e] += rv[e];
-            }
-            if (a.y2) vec_store<VW>(a.y2 + oy, vals);
-            if (a.relu) {
-#pragma unroll
-              for (int e = 0; e < VW; ++e) vals[e] = act_apply(a.relu, vals[e]);
-            }
-            if (a.dact) {
-              float zv[VW];
-              vec_load<VW>(a.dact + o, zv);
-#pragma unroll
-              for (int e = 0; e < VW; ++e) vals[e] *= act_gelu_grad(zv[e]);
-            }
-          }
-          vec_store<VW>(yout + oy, vals);
+      for (int r = 0; r < 4; ++r) {
+        if constexpr (FM == 4) {
+          *reinterpret_cast<float4*>(&st[li * Cfg::ST_STRIDE + 16 * lg + 4 * r]) =
+              make_float4(acc[0][jn][r], acc[1][jn][r], acc[2][jn][r], acc[3][jn][r]);
+        } else {
+          *reinterpret_cast<float2*>(&st[li * Cfg::ST_STRIDE + 8 * lg + 2 * r]) = make_float2(acc[0][jn][r], acc[1][jn][r]);
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int i = 0; i < 16 / RPI; ++i) {
+        const int row = rrow + RPI * i;
+        float v = st[row * Cfg::ST_STRIDE + rcol];
+        if (mok) {
+          const int n = n0 + wn * Cfg::WN + FN * row + jn;
+          const size_t o = (size_t)(bb * a.Cout + n) * a.THWo + pp;
+          const size_t oy = fused ? (size_t)bb * a.y_bstride + (size_t)n * a.THWo + pp : o;
+          if (fused) {
+            if (a.ln_u) v = v * a.ln_rs[mm] - a.ln_u[n] * (a.ln_mu[mm] * a.ln_rs[mm]);
+            v = v * a.scale[n] + a.shift[n];
+            if (a.res) v += a.res[o];
+            if (a.y2) a.y2[oy] = v;
+            if (a.relu) v = act_apply(a.relu, v);
+            if (a.dact) v *= act_gelu_grad(a.dact[o]);
+          }
+          yout[oy] = v;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-  };
-  if (a.vw == 2) emit(std::integral_constant<int, 2>{});
-  else emit(std::integral_constant<int, 1>{});
+  }
 }
 
 template <int BM, int BN, int BK>
