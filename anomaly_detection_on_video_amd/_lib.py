@@ -107,6 +107,12 @@ SIGNATURES = {
     "advhip_maxpool3d_padded_f32": (C.c_int, [_P, _P] + [_I] * 14 + [_P]),
     "advhip_maxpool3d_strided_f32": (C.c_int, [_P, _P, _L] + [_I] * 11 + [_P]),
     "advhip_global_avgpool_f32": (C.c_int, [_P, _P, _L, _I, _P]),
+    "advhip_chan_layernorm_fwd_f32": (C.c_int, [_P] * 6 + [_I, _L, C.c_float, _P]),
+    "advhip_chan_layernorm_bwd_partial_rows": (_L, [_L]),
+    "advhip_chan_layernorm_bwd_f32": (C.c_int, [_P] * 8 + [_I, _L, C.c_float, _P]),
+    "advhip_dwconv_t_fwd_f32": (C.c_int, [_P] * 4 + [_I, _I, _L, _I, _I, _P]),
+    "advhip_dwconv_t_bwd_chunks": (_I, [_I, _L]),
+    "advhip_dwconv_t_bwd_f32": (C.c_int, [_P] * 5 + [_I, _I, _L, _I, _I, _P]),
     "advhip_mil_magnitude_f32": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "advhip_mil_topk_select_f32": (C.c_int, [_P] * 7 + [_I] * 5 + [_P]),
     "advhip_mil_topk_select_bwd_f32": (C.c_int, [_P] * 5 + [_I] * 5 + [_P]),

@@ -1,0 +1,210 @@
+// Fused element-wise / reduction kernels of the MGFN scorer body on (C, N) activations (channels outermost, N = B*T
+// positions contiguous), forward and backward -- the work between the GEMM-shaped layers that the torch formulation
+// spends ~10 passes over the activation on:
+//   chan_layernorm   MGFNLayerNorm over channels, (x - mean) / (sqrt(var_biased) + eps) * g + b
+//                    (/root/reference/src/models/mgfn/modeling_mgfn.py:36-46)
+//   dwconv_t         FocusAttention.rel_pos: per-head depth-wise temporal Conv1d(heads, heads, k, padding=k/2, groups=heads)
+//                    applied to "b (c h) n -> (b c) h n" (modeling_mgfn.py:169-171, 176-178): channel c uses filter c % heads
+// All reductions are deterministic (fixed-order partial sums, no atomics).
+#include <algorithm>
+
+#include "common.h"
+
+namespace advhip {
+
+constexpr int LN_COLS = 64;  // positions per block (one per lane); the block's 4 waves split the channels
+
+// y = (x - mu) * rs * g + b;  mu / rs per position are outputs too (saved for the backward pass)
+__global__ __launch_bounds__(256) void chan_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                 const float* __restrict__ b, float* __restrict__ y,
+                                                                 float* __restrict__ mu, float* __restrict__ rs, int Cc, long long N,
+                                                                 float eps) {
+  __shared__ float part[4][LN_COLS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long n = blockIdx.x * (long long)LN_COLS + lane;
+  const bool ok = n < N;
+  float s = 0.f;
+  if (ok)
+    for (int c = w; c < Cc; c += 4) s += x[(long long)c * N + n];
+  part[w][lane] = s;
+  __syncthreads();
+  const float mean = (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]) / (float)Cc;
+  __syncthreads();
+  float q = 0.f;
+  if (ok)
+    for (int c = w; c < Cc; c += 4) {
+      const float d = x[(long long)c * N + n] - mean;
+      q += d * d;
+    }
+  part[w][lane] = q;
+  __syncthreads();
+  const float var = (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]) / (float)Cc;
+  const float r = 1.f / (sqrtf(var) + eps);
+  if (!ok) return;
+  if (w == 0) { mu[n] = mean; rs[n] = r; }
+  for (int c = w; c < Cc; c += 4) y[(long long)c * N + n] = (x[(long long)c * N + n] - mean) * r * g[c] + b[c];
+}
+
+// With xc = x - mu, r = rs, sigma = 1/r - eps, dyg = dy * g:
+//   dx = r * (dyg - mean_c(dyg)) - r^2 / sigma * mean_c(dyg * xc) * xc
+//   dg[c] = sum_n dy * xc * r,  db[c] = sum_n dy        (written as per-block partial sums pg / pb [blocks][C])
+__global__ __launch_bounds__(256) void chan_layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 const float* __restrict__ g, const float* __restrict__ mu,
+                                                                 const float* __restrict__ rs, float* __restrict__ dx,
+                                                                 float* __restrict__ pg, float* __restrict__ pb, int Cc, long long N,
+                                                                 float eps) {
+  __shared__ float part[2][4][LN_COLS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long n = blockIdx.x * (long long)LN_COLS + lane;
+  const bool ok = n < N;
+  const float mean = ok ? mu[n] : 0.f, r = ok ? rs[n] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = w; c < Cc; c += 4) {
+    float d = 0.f, xc = 0.f;
+    if (ok) {
+      d = dy[(long long)c * N + n];
+      xc = x[(long long)c * N + n] - mean;
+    }
+    const float dyg = d * g[c];
+    s1 += dyg;
+    s2 += dyg * xc;
+    // per-channel sums over the block's 64 positions (wave reduction, fixed order)
+    float a = d * xc * r, bsum = d;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a += __shfl_xor(a, off, 64);
+      bsum += __shfl_xor(bsum, off, 64);
+    }
+    if (lane == 0) {
+      pg[(long long)blockIdx.x * Cc + c] = a;
+      pb[(long long)blockIdx.x * Cc + c] = bsum;
+    }
+  }
+  part[0][w][lane] = s1;
+  part[1][w][lane] = s2;
+  __syncthreads();
+  if (!ok) return;
+  const float m1 = (part[0][0][lane] + part[0][1][lane] + part[0][2][lane] + part[0][3][lane]) / (float)Cc;
+  const float m2 = (part[1][0][lane] + part[1][1][lane] + part[1][2][lane] + part[1][3][lane]) / (float)Cc;
+  const float sigma = 1.f / r - eps;
+  const float k2 = sigma > 0.f ? r * r / sigma * m2 : 0.f;
+  for (int c = w; c < Cc; c += 4) {
+    const long long o = (long long)c * N + n;
+    dx[o] = r * (dy[o] * g[c] - m1) - k2 * (x[o] - mean);
+  }
+}
+
+// out[c, b, t] = bias[c % H] + sum_j w[c % H][j] * v[c, b, t + j - K/2]   (zero outside [0, T)); one thread per element
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_t_fwd_kernel(const float* __restrict__ v, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out, int H, int T,
+                                                           long long rows_per_c, long long total) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int t = (int)(i % T);
+    const int h = (int)((i / (rows_per_c * T)) % H);
+    float acc = bias[h];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int tt = t + j - K / 2;
+      if (tt >= 0 && tt < T) acc += w[h * K + j] * v[i + j - K / 2];
+    }
+    out[i] = acc;
+  }
+}
+
+// dv[c, b, t] = sum_j w[h][j] * dout[c, b, t - j + K/2];  per block (one channel c, a chunk of its B*T elements):
+// partial[blk][0..K-1] = sum dout[c,b,t] * v[c,b,t+j-K/2],  partial[blk][K] = sum dout
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_t_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ v,
+                                                           const float* __restrict__ w, float* __restrict__ dv,
+                                                           float* __restrict__ partial, int H, int T, long long per_c, int chunks) {
+  __shared__ float red[4][K + 1];
+  const int c = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  const int h = c % H;
+  const long long lo = (per_c * chunk) / chunks, hi = (per_c * (chunk + 1)) / chunks;  // whole rows: per_c / chunks is a multiple of T
+  float acc[K + 1];
+#pragma unroll
+  for (int j = 0; j <= K; ++j) acc[j] = 0.f;
+  for (long long e = lo + threadIdx.x; e < hi; e += 256) {
+    const long long i = (long long)c * per_c + e;
+    const int t = (int)(e % T);
+    const float d = dout[i];
+    float g = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int tv = t + j - K / 2;   // v index this output touched with tap j
+      if (tv >= 0 && tv < T) acc[j] += d * v[i + j - K / 2];
+      const int td = t - j + K / 2;   // output that touched v[t] with tap j
+      if (td >= 0 && td < T) g += w[h * K + j] * dout[i - j + K / 2];
+    }
+    acc[K] += d;
+    dv[i] = g;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j <= K; ++j) {
+    float a = acc[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    if (lane == 0) red[wv][j] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x <= K) partial[(long long)blockIdx.x * (K + 1) + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+}  // namespace advhip
+
+using namespace advhip;
+
+extern "C" int advhip_chan_layernorm_fwd_f32(const float* x, const float* g, const float* b, float* y, float* mu, float* rs,
+                                             int32_t C, int64_t N, float eps, void* stream) {
+  ADVHIP_REQUIRE(x && g && b && y && mu && rs && C > 0 && N > 0, "chan_layernorm_fwd: bad arguments");
+  const long long blocks = (N + LN_COLS - 1) / LN_COLS;
+  ADVHIP_REQUIRE(blocks < (1ll << 31), "chan_layernorm_fwd: too many positions");
+  hipLaunchKernelGGL(chan_layernorm_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, g, b, y, mu, rs, C,
+                     (long long)N, eps);
+  return check_launch("chan_layernorm_fwd");
+}
+
+extern "C" int64_t advhip_chan_layernorm_bwd_partial_rows(int64_t N) { return (N + LN_COLS - 1) / LN_COLS; }
+
+extern "C" int advhip_chan_layernorm_bwd_f32(const float* dy, const float* x, const float* g, const float* mu, const float* rs,
+                                             float* dx, float* dg_partial, float* db_partial, int32_t C, int64_t N, float eps,
+                                             void* stream) {
+  ADVHIP_REQUIRE(dy && x && g && mu && rs && dx && dg_partial && db_partial && C > 0 && N > 0, "chan_layernorm_bwd: bad arguments");
+  const long long blocks = (N + LN_COLS - 1) / LN_COLS;
+  ADVHIP_REQUIRE(blocks < (1ll << 31), "chan_layernorm_bwd: too many positions");
+  hipLaunchKernelGGL(chan_layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, x, g, mu, rs, dx,
+                     dg_partial, db_partial, C, (long long)N, eps);
+  return check_launch("chan_layernorm_bwd");
+}
+
+extern "C" int advhip_dwconv_t_fwd_f32(const float* v, const float* w, const float* bias, float* out, int32_t C, int32_t H,
+                                       int64_t rows, int32_t T, int32_t K, void* stream) {
+  ADVHIP_REQUIRE(v && w && bias && out && C > 0 && H > 0 && rows > 0 && T > 0 && C % H == 0, "dwconv_t_fwd: bad arguments");
+  ADVHIP_REQUIRE(K == 5 || K == 3, "dwconv_t: kernel size %d (3 and 5 are instantiated)", K);
+  const long long total = (long long)C * rows * T;
+  const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 32);
+  if (K == 5) hipLaunchKernelGGL(dwconv_t_fwd_kernel<5>, dim3(grid), dim3(256), 0, (hipStream_t)stream, v, w, bias, out, H, T, (long long)rows, total);
+  else hipLaunchKernelGGL(dwconv_t_fwd_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, v, w, bias, out, H, T, (long long)rows, total);
+  return check_launch("dwconv_t_fwd");
+}
+
+extern "C" int32_t advhip_dwconv_t_bwd_chunks(int32_t C, int64_t rows) {
+  // blocks per channel: enough blocks for the chip, whole rows per block
+  int chunks = 1;
+  while ((long long)C * chunks < 2048 && rows % (chunks * 2) == 0) chunks *= 2;
+  return chunks;
+}
+
+extern "C" int advhip_dwconv_t_bwd_f32(const float* dout, const float* v, const float* w, float* dv, float* partial, int32_t C,
+                                       int32_t H, int64_t rows, int32_t T, int32_t K, void* stream) {
+  ADVHIP_REQUIRE(dout && v && w && dv && partial && C > 0 && H > 0 && rows > 0 && T > 0 && C % H == 0, "dwconv_t_bwd: bad arguments");
+  ADVHIP_REQUIRE(K == 5 || K == 3, "dwconv_t: kernel size %d (3 and 5 are instantiated)", K);
+  const int chunks = advhip_dwconv_t_bwd_chunks(C, rows);
+  const long long per_c = (long long)rows * T;
+  const dim3 grid((unsigned)((long long)C * chunks));
+  if (K == 5) hipLaunchKernelGGL(dwconv_t_bwd_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, dout, v, w, dv, partial, H, T, per_c, chunks);
+  else hipLaunchKernelGGL(dwconv_t_bwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, dout, v, w, dv, partial, H, T, per_c, chunks);
+  return check_launch("dwconv_t_bwd");
+}

@@ -191,3 +191,78 @@ def ffn_cn_folded_ln(x: torch.Tensor, norm, in_conv: torch.nn.Conv1d, out_conv: 
     shift = in_conv.bias + w1 @ norm.b.view(dim)
     h = conv_cn(x, pack_kc(wg.view(hid, dim, 1)), hid, 1, shift=shift, act=ACT_GELU, ln=(wg.sum(1).contiguous(), mu, rs))
     return conv_cn(h, pack_kc(out_conv.weight), dim, 1, shift=out_conv.bias, residual=x)
+
+
+# ---- fused element-wise layers (csrc/mgfn.hip) -------------------------------------------------------------------------
+class _ChanLayerNorm(torch.autograd.Function):
+    """MGFNLayerNorm over the channels of a (C, B, T) activation: one launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        c = x.shape[0]
+        n = x.numel() // c
+        y = torch.empty_like(x)
+        mu = torch.empty((n,), device=x.device, dtype=torch.float32)
+        rs = torch.empty_like(mu)
+        gf, bf = g.detach().reshape(c).contiguous(), b.detach().reshape(c).contiguous()
+        check(_lib.load().advhip_chan_layernorm_fwd_f32(ptr(x), ptr(gf), ptr(bf), ptr(y), ptr(mu), ptr(rs), c, n, C.c_float(eps), stream()),
+              "chan_layernorm_fwd")
+        ctx.save_for_backward(x, gf, mu, rs)
+        ctx.eps, ctx.gshape = eps, g.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gf, mu, rs = ctx.saved_tensors
+        c = x.shape[0]
+        n = x.numel() // c
+        dy = dy.contiguous()
+        lib = _lib.load()
+        rows = lib.advhip_chan_layernorm_bwd_partial_rows(n)
+        dx = torch.empty_like(x)
+        pg = torch.empty((rows, c), device=x.device, dtype=torch.float32)
+        pb = torch.empty_like(pg)
+        check(lib.advhip_chan_layernorm_bwd_f32(ptr(dy), ptr(x), ptr(gf), ptr(mu), ptr(rs), ptr(dx), ptr(pg), ptr(pb), c, n,
+                                                C.c_float(ctx.eps), stream()), "chan_layernorm_bwd")
+        return dx, pg.sum(0).view(ctx.gshape), pb.sum(0).view(ctx.gshape), None
+
+
+class _DWConvT(torch.autograd.Function):
+    """FocusAttention.rel_pos on a (C, B, T) activation (channel c -> head c % H): one launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, v, weight, bias):
+        c, b, t = v.shape
+        h, _, k = weight.shape
+        out = torch.empty_like(v)
+        w2 = weight.detach().reshape(h, k).contiguous()
+        check(_lib.load().advhip_dwconv_t_fwd_f32(ptr(v), ptr(w2), ptr(bias.detach().contiguous()), ptr(out), c, h, b, t, k, stream()), "dwconv_t_fwd")
+        ctx.save_for_backward(v, w2)
+        ctx.wshape = weight.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        v, w2 = ctx.saved_tensors
+        c, b, t = v.shape
+        h, k = w2.shape
+        dout = dout.contiguous()
+        lib = _lib.load()
+        chunks = lib.advhip_dwconv_t_bwd_chunks(c, b)
+        dv = torch.empty_like(v)
+        partial = torch.empty((c * chunks, k + 1), device=v.device, dtype=torch.float32)
+        check(lib.advhip_dwconv_t_bwd_f32(ptr(dout), ptr(v), ptr(w2), ptr(dv), ptr(partial), c, h, b, t, k, stream()), "dwconv_t_bwd")
+        per_head = partial.view(c // h, h, chunks, k + 1).sum(dim=(0, 2))  # channel = c_idx * H + h_idx
+        return dv, per_head[:, :k].reshape(ctx.wshape), per_head[:, k].contiguous()
+
+
+def fused_ok(x: torch.Tensor) -> bool:
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 3
+
+
+def chan_layernorm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
+    return _ChanLayerNorm.apply(x.contiguous(), g, b, eps)
+
+
+def dwconv_t(v: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    return _DWConvT.apply(v.contiguous(), weight, bias)

@@ -127,6 +127,8 @@ class MGFNLayerNorm(nn.Module):
         self.b = nn.Parameter(torch.zeros(1, dim, 1))
 
     def forward(self, x):  # x: (C, B, T)
+        if mgfn_ops.fused_ok(x):  # one HIP launch forward, one backward (csrc/mgfn.hip)
+            return mgfn_ops.chan_layernorm(x, self.g, self.b, self.eps)
         var, mean = torch.var_mean(x, dim=0, unbiased=False, keepdim=True)
         return (x - mean) / (var.sqrt() + self.eps) * self.g.view(-1, 1, 1) + self.b.view(-1, 1, 1)
 
@@ -225,6 +227,9 @@ class FocusAttention(nn.Module):
         h = self.heads
         v = v.view(inner // h, h, b, n)  # channel = c_idx*heads + h_idx  ("b (c h) n -> (b c) h n")
         k = self.rel_pos.weight.shape[-1]
+        if mgfn_ops.fused_ok(v) and k in (3, 5):  # the per-head depth-wise temporal conv as one HIP launch (fwd) / one (bwd)
+            out = mgfn_ops.dwconv_t(v.reshape(inner, b, n), self.rel_pos.weight, self.rel_pos.bias)
+            return _pointwise(self.to_out, out, residual)
         vp = F.pad(v, (k // 2, k // 2))
         w = self.rel_pos.weight[:, 0]  # (h, k): one temporal filter per head
         out = self.rel_pos.bias.view(1, h, 1, 1)

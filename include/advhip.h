@@ -230,6 +230,28 @@ int advhip_gemm_nt_f32(const float* A, const float* B, float* C, int32_t M, int3
  * src/i3d.py:174-175; the attention softmax of GlanceAttention, modeling_mgfn.py:115-120).  x == y allowed. */
 int advhip_softmax_rows_f32(const float* x, float* y, int64_t rows, int32_t n, float scale, void* stream);
 
+/* --- MGFN body: fused element-wise / reduction kernels on (C, N) activations (channels outermost) --------------------
+ * MGFNLayerNorm over the channel dim (modeling_mgfn.py:36-46): y = (x - mean_c) / (sqrt(var_biased_c) + eps) * g[c] + b[c]
+ * per position n; mu / rs (= 1 / (std + eps)) per position are returned for the backward pass. */
+int advhip_chan_layernorm_fwd_f32(const float* x, const float* g, const float* b, float* y, float* mu, float* rs, int32_t C,
+                                  int64_t N, float eps, void* stream);
+/* Its backward: dx (C, N), and per-block partial sums of dg / db as [advhip_chan_layernorm_bwd_partial_rows(N)][C] matrices
+ * (the caller sums the rows: fixed order, no atomics). */
+int64_t advhip_chan_layernorm_bwd_partial_rows(int64_t N);
+int advhip_chan_layernorm_bwd_f32(const float* dy, const float* x, const float* g, const float* mu, const float* rs, float* dx,
+                                  float* dg_partial, float* db_partial, int32_t C, int64_t N, float eps, void* stream);
+
+/* FocusAttention.rel_pos (modeling_mgfn.py:169-171, 176-178): depth-wise temporal conv, one K-tap filter per head, on a
+ * (C, rows, T) activation whose channel c belongs to head c % H: out[c,r,t] = bias[h] + sum_j w[h][j] * v[c,r,t+j-K/2]
+ * (zero padding).  K in {3, 5}. */
+int advhip_dwconv_t_fwd_f32(const float* v, const float* w, const float* bias, float* out, int32_t C, int32_t H, int64_t rows,
+                            int32_t T, int32_t K, void* stream);
+/* Backward: dv, and partial[C * chunks][K + 1] = per-block sums of (dout * v shifted by tap j, j < K; dout) -- the caller
+ * adds the blocks of every channel of a head (chunks = advhip_dwconv_t_bwd_chunks(C, rows)). */
+int32_t advhip_dwconv_t_bwd_chunks(int32_t C, int64_t rows);
+int advhip_dwconv_t_bwd_f32(const float* dout, const float* v, const float* w, float* dv, float* partial, int32_t C, int32_t H,
+                            int64_t rows, int32_t T, int32_t K, void* stream);
+
 /* --- MIL scorer (MGFN head) -----------------------------------------------------------------
  * Fused magnitude / score reduction of magnitude_selection_and_score_prediction
  * (src/models/mgfn/modeling_mgfn.py:314-319): for features (bs*ncrops, T, F) and per-crop scores

@@ -266,6 +266,7 @@ def test_hip_gemm_path_matches_torch_path_forward_and_every_gradient(model_and_s
         with monkeypatch.context() as mp:
             if not hip:
                 mp.setattr(mgfn_ops, "eligible", lambda *a: False)
+                mp.setattr(mgfn_ops, "fused_ok", lambda x: False)
             mp.setattr(mgfn_ops, "conv_cn", counting)
             if grad:
                 o = model(video=video, abnormal_labels=al, normal_labels=nl)
@@ -287,3 +288,50 @@ def test_hip_gemm_path_matches_torch_path_forward_and_every_gradient(model_and_s
     e_t, _, _ = run(False, False)
     assert rel_err(e_h.cpu(), e_t.cpu()) < 1e-5
     model.injected_keep = None
+
+
+@pytest.mark.parametrize("shape", [(1024, 7, 32), (64, 3, 57), (128, 10, 1), (96, 2, 33)])
+def test_chan_layernorm_fwd_bwd_vs_torch_fp64(shape):
+    """csrc/mgfn.hip chan_layernorm vs MGFNLayerNorm's formula ((x - mean) / (sqrt(var_biased) + eps) * g + b over
+    channels, modeling_mgfn.py:43-46) in fp64 autograd: output, dx, dg, db."""
+    from anomaly_detection_on_video_amd import mgfn_ops
+
+    c = shape[0]
+    x = synth_tensor(f"ln.x{shape}", shape, scale=2.0, offset=0.7)
+    g = synth_tensor(f"ln.g{shape}", (1, c, 1), scale=0.25, offset=1.0)
+    b = synth_tensor(f"ln.b{shape}", (1, c, 1), scale=0.1)
+    dy = synth_tensor(f"ln.dy{shape}", shape, scale=1.0)
+    xd, gd, bd = (t.double().requires_grad_(True) for t in (x, g, b))
+    var, mean = torch.var_mean(xd, dim=0, unbiased=False, keepdim=True)
+    ref = (xd - mean) / (var.sqrt() + 1e-5) * gd.view(-1, 1, 1) + bd.view(-1, 1, 1)
+    ref.backward(dy.double())
+    xg, gg, bg = (t.to(DEV).requires_grad_(True) for t in (x, g, b))
+    out = mgfn_ops.chan_layernorm(xg, gg, bg, 1e-5)
+    out.backward(dy.to(DEV))
+    assert rel_err(out.detach().cpu(), ref.detach()) < 1e-5
+    assert rel_err(xg.grad.cpu(), xd.grad) < 1e-4
+    assert rel_err(gg.grad.cpu(), gd.grad) < 1e-4 and rel_err(bg.grad.cpu(), bd.grad) < 1e-5
+
+
+@pytest.mark.parametrize("c,heads,b,t,k", [(1024, 16, 20, 32, 5), (128, 2, 6, 57, 5), (64, 4, 3, 2, 5), (32, 8, 5, 9, 3)])
+def test_dwconv_t_fwd_bwd_vs_torch_conv1d(c, heads, b, t, k):
+    """csrc/mgfn.hip dwconv_t vs the reference formulation: rearrange 'b (c h) n -> (b c) h n', Conv1d(heads, heads, k,
+    padding=k//2, groups=heads), rearrange back (modeling_mgfn.py:169-171, 176-178) -- in fp64 autograd."""
+    from anomaly_detection_on_video_amd import mgfn_ops
+
+    v = synth_tensor(f"dw.v{c}{t}", (c, b, t), scale=1.5)
+    w = synth_tensor(f"dw.w{c}{t}", (heads, 1, k), scale=0.5)
+    bias = synth_tensor(f"dw.b{c}{t}", (heads,), scale=0.2)
+    dout = synth_tensor(f"dw.d{c}{t}", (c, b, t), scale=1.0)
+    vd, wd, bd = (x.double().requires_grad_(True) for x in (v, w, bias))
+    xb = vd.permute(1, 0, 2)                                   # (b, C, n) as the reference holds it
+    xr = xb.reshape(b, c // heads, heads, t).reshape(b * (c // heads), heads, t)
+    yr = torch.nn.functional.conv1d(xr, wd, bd, padding=k // 2, groups=heads)
+    ref = yr.reshape(b, c // heads, heads, t).reshape(b, c, t).permute(1, 0, 2)
+    ref.backward(dout.double())
+    vg, wg, bg = (x.to(DEV).requires_grad_(True) for x in (v, w, bias))
+    out = mgfn_ops.dwconv_t(vg, wg, bg)
+    out.backward(dout.to(DEV))
+    assert rel_err(out.detach().cpu(), ref.detach()) < 1e-5
+    assert rel_err(vg.grad.cpu(), vd.grad) < 1e-5
+    assert rel_err(wg.grad.cpu(), wd.grad) < 1e-4 and rel_err(bg.grad.cpu(), bd.grad) < 1e-4
