@@ -96,6 +96,8 @@ def test_run_py_trains_on_synthetic_corpus(tmp_path):
     from anomaly_detection_on_video_amd.runner import VideoAnomalyDetectionRunner, load_checkpoint
 
     r = VideoAnomalyDetectionRunner(MGFNForVideoAnomalyDetection(MGFNConfig()), {"learning_rate": 1e-3, "weight_decay": 5e-4}, {"frames_per_clip": 16})
+    state = torch.load(os.path.join(ckpt, "last.ckpt"), map_location="cpu", weights_only=False)  # rewritten by the resumed run
+    assert state["epoch"] == 2 and state["global_step"] == 6
     load_checkpoint(os.path.join(ckpt, "last.ckpt"), r)
     assert torch.equal(r.model.fc.weight, state["state_dict"]["model.fc.weight"])
     old = str(tmp_path / "old.pt")
