@@ -110,6 +110,8 @@ SIGNATURES = {
     "advhip_chan_layernorm_fwd_f32": (C.c_int, [_P] * 6 + [_I, _L, C.c_float, _P]),
     "advhip_chan_layernorm_bwd_partial_rows": (_L, [_L]),
     "advhip_chan_layernorm_bwd_f32": (C.c_int, [_P] * 8 + [_I, _L, C.c_float, _P]),
+    "advhip_bn_rows_fwd_f32": (C.c_int, [_P] * 6 + [_I, _L, C.c_float, _P]),
+    "advhip_bn_rows_bwd_f32": (C.c_int, [_P] * 8 + [_I, _L, C.c_float, _P]),
     "advhip_dwconv_t_fwd_f32": (C.c_int, [_P] * 4 + [_I, _I, _L, _I, _I, _P]),
     "advhip_dwconv_t_bwd_chunks": (_I, [_I, _L]),
     "advhip_dwconv_t_bwd_f32": (C.c_int, [_P] * 5 + [_I, _I, _L, _I, _I, _P]),

@@ -152,9 +152,83 @@ __global__ __launch_bounds__(256) void dwconv_t_bwd_kernel(const float* __restri
   if (threadIdx.x <= K) partial[(long long)blockIdx.x * (K + 1) + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// ---- BatchNorm1d over the rows of a (C, N) activation (FocusAttention.norm, modeling_mgfn.py:162, 174) -------------------
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();  // red may still be read from a previous call
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// training mode: batch statistics per channel (one block per channel row); y = (x - mean) * rstd * gamma + beta;
+// mean / biased var are returned (running-statistics update and backward)
+__global__ __launch_bounds__(256) void bn_rows_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ y,
+                                                          float* __restrict__ mean_out, float* __restrict__ var_out, long long N,
+                                                          float eps) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  const float* xr = x + (long long)c * N;
+  float s = 0.f;
+  for (long long i = threadIdx.x; i < N; i += 256) s += xr[i];
+  const float mean = block_sum_256(s, red) / (float)N;
+  float q = 0.f;
+  for (long long i = threadIdx.x; i < N; i += 256) {
+    const float d = xr[i] - mean;
+    q += d * d;
+  }
+  const float var = block_sum_256(q, red) / (float)N;
+  const float sc = gamma[c] * rsqrtf(var + eps), sh = beta[c] - mean * sc;
+  float* yr = y + (long long)c * N;
+  for (long long i = threadIdx.x; i < N; i += 256) yr[i] = xr[i] * sc + sh;
+  if (threadIdx.x == 0) { mean_out[c] = mean; var_out[c] = var; }
+}
+
+// dx = gamma * rstd * (dy - mean(dy) - xhat * mean(dy * xhat)),  dgamma = sum dy * xhat,  dbeta = sum dy
+__global__ __launch_bounds__(256) void bn_rows_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                          const float* __restrict__ var, float* __restrict__ dx,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, long long N, float eps) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  const float* xr = x + (long long)c * N;
+  const float* dr = dy + (long long)c * N;
+  const float mu = mean[c], rstd = rsqrtf(var[c] + eps);
+  float s1 = 0.f, s2 = 0.f;
+  for (long long i = threadIdx.x; i < N; i += 256) {
+    const float d = dr[i];
+    s1 += d;
+    s2 += d * (xr[i] - mu) * rstd;
+  }
+  const float sum_dy = block_sum_256(s1, red);
+  const float sum_dyx = block_sum_256(s2, red);
+  const float k = gamma[c] * rstd, m1 = sum_dy / (float)N, m2 = sum_dyx / (float)N;
+  float* o = dx + (long long)c * N;
+  for (long long i = threadIdx.x; i < N; i += 256) o[i] = k * (dr[i] - m1 - (xr[i] - mu) * rstd * m2);
+  if (threadIdx.x == 0) { dgamma[c] = sum_dyx; dbeta[c] = sum_dy; }
+}
+
 }  // namespace advhip
 
 using namespace advhip;
+
+extern "C" int advhip_bn_rows_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* var,
+                                      int32_t C, int64_t N, float eps, void* stream) {
+  ADVHIP_REQUIRE(x && gamma && beta && y && mean && var && C > 0 && N > 0, "bn_rows_fwd: bad arguments");
+  hipLaunchKernelGGL(bn_rows_fwd_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, var, (long long)N, eps);
+  return check_launch("bn_rows_fwd");
+}
+
+extern "C" int advhip_bn_rows_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* var,
+                                      float* dx, float* dgamma, float* dbeta, int32_t C, int64_t N, float eps, void* stream) {
+  ADVHIP_REQUIRE(dy && x && gamma && mean && var && dx && dgamma && dbeta && C > 0 && N > 0, "bn_rows_bwd: bad arguments");
+  hipLaunchKernelGGL(bn_rows_bwd_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, var, dx, dgamma, dbeta,
+                     (long long)N, eps);
+  return check_launch("bn_rows_bwd");
+}
 
 extern "C" int advhip_chan_layernorm_fwd_f32(const float* x, const float* g, const float* b, float* y, float* mu, float* rs,
                                              int32_t C, int64_t N, float eps, void* stream) {

@@ -266,3 +266,38 @@ def chan_layernorm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, eps: float
 
 def dwconv_t(v: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     return _DWConvT.apply(v.contiguous(), weight, bias)
+
+
+class _BNRowsTrain(torch.autograd.Function):
+    """Training-mode BatchNorm1d on a (C, B, T) activation: batch statistics, one launch forward, one backward.
+    Returns (y, batch mean, biased batch variance); the running-statistics update stays with the caller."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        c = x.shape[0]
+        n = x.numel() // c
+        y = torch.empty_like(x)
+        mean = torch.empty((c,), device=x.device, dtype=torch.float32)
+        var = torch.empty_like(mean)
+        check(_lib.load().advhip_bn_rows_fwd_f32(ptr(x), ptr(gamma.detach()), ptr(beta.detach()), ptr(y), ptr(mean), ptr(var), c, n,
+                                                 C.c_float(eps), stream()), "bn_rows_fwd")
+        ctx.save_for_backward(x, gamma, mean, var)
+        ctx.eps = eps
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        x, gamma, mean, var = ctx.saved_tensors
+        c = x.shape[0]
+        n = x.numel() // c
+        dx = torch.empty_like(x)
+        dg = torch.empty((c,), device=x.device, dtype=torch.float32)
+        db = torch.empty_like(dg)
+        check(_lib.load().advhip_bn_rows_bwd_f32(ptr(dy.contiguous()), ptr(x), ptr(gamma.detach()), ptr(mean), ptr(var), ptr(dx), ptr(dg),
+                                                 ptr(db), c, n, C.c_float(ctx.eps), stream()), "bn_rows_bwd")
+        return dx, dg, db, None
+
+
+def bn_rows_train(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
+    return _BNRowsTrain.apply(x.contiguous(), gamma, beta, eps)

@@ -206,6 +206,16 @@ class FocusAttention(nn.Module):
 
     def _batch_norm(self, x):  # nn.BatchNorm1d semantics on a (C, B, T) tensor
         bn = self.norm
+        if bn.training and mgfn_ops.fused_ok(x):  # batch statistics + normalisation: one HIP launch (fwd) / one (bwd)
+            y, mean, var = mgfn_ops.bn_rows_train(x, bn.weight, bn.bias, bn.eps)
+            if bn.track_running_stats:
+                with torch.no_grad():
+                    n = x.shape[1] * x.shape[2]
+                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                    bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                    bn.running_var.mul_(1 - mom).add_(var * (n / max(n - 1, 1)), alpha=mom)
+                    bn.num_batches_tracked += 1
+            return y
         if bn.training:
             var, mean = torch.var_mean(x, dim=(1, 2), unbiased=False)
             if bn.track_running_stats:
@@ -227,7 +237,7 @@ class FocusAttention(nn.Module):
         h = self.heads
         v = v.view(inner // h, h, b, n)  # channel = c_idx*heads + h_idx  ("b (c h) n -> (b c) h n")
         k = self.rel_pos.weight.shape[-1]
-        if mgfn_ops.fused_ok(v) and k in (3, 5):  # the per-head depth-wise temporal conv as one HIP launch (fwd) / one (bwd)
+        if mgfn_ops.fused_ok(x) and k in (3, 5):  # the per-head depth-wise temporal conv as one HIP launch (fwd) / one (bwd)
             out = mgfn_ops.dwconv_t(v.reshape(inner, b, n), self.rel_pos.weight, self.rel_pos.bias)
             return _pointwise(self.to_out, out, residual)
         vp = F.pad(v, (k // 2, k // 2))

@@ -241,6 +241,14 @@ int64_t advhip_chan_layernorm_bwd_partial_rows(int64_t N);
 int advhip_chan_layernorm_bwd_f32(const float* dy, const float* x, const float* g, const float* mu, const float* rs, float* dx,
                                   float* dg_partial, float* db_partial, int32_t C, int64_t N, float eps, void* stream);
 
+/* nn.BatchNorm1d in training mode on a (C, N) activation (FocusAttention.norm, modeling_mgfn.py:162, 174): batch statistics
+ * per channel row, y = (x - mean) * rsqrt(var_biased + eps) * gamma + beta; mean / var are returned (running-statistics
+ * update by the caller, backward).  Backward: dx, dgamma, dbeta. */
+int advhip_bn_rows_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* var, int32_t C,
+                           int64_t N, float eps, void* stream);
+int advhip_bn_rows_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* var, float* dx,
+                           float* dgamma, float* dbeta, int32_t C, int64_t N, float eps, void* stream);
+
 /* FocusAttention.rel_pos (modeling_mgfn.py:169-171, 176-178): depth-wise temporal conv, one K-tap filter per head, on a
  * (C, rows, T) activation whose channel c belongs to head c % H: out[c,r,t] = bias[h] + sum_j w[h][j] * v[c,r,t+j-K/2]
  * (zero padding).  K in {3, 5}. */

@@ -335,3 +335,26 @@ def test_dwconv_t_fwd_bwd_vs_torch_conv1d(c, heads, b, t, k):
     assert rel_err(out.detach().cpu(), ref.detach()) < 1e-5
     assert rel_err(vg.grad.cpu(), vd.grad) < 1e-5
     assert rel_err(wg.grad.cpu(), wd.grad) < 1e-4 and rel_err(bg.grad.cpu(), bd.grad) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(1024, 10, 32), (128, 3, 57), (64, 1, 2)])
+def test_bn_rows_train_fwd_bwd_vs_torch_batchnorm1d(shape):
+    """csrc/mgfn.hip bn_rows (training-mode nn.BatchNorm1d on a (C, B, T) activation) vs torch's BatchNorm1d on the
+    reference's (B, C, T) layout in fp64 autograd: output, batch statistics, dx, dgamma, dbeta."""
+    from anomaly_detection_on_video_amd import mgfn_ops
+
+    c = shape[0]
+    x = synth_tensor(f"bn.x{shape}", shape, scale=2.0, offset=0.3)
+    g = synth_tensor(f"bn.g{shape}", (c,), scale=0.25, offset=1.0)
+    b = synth_tensor(f"bn.b{shape}", (c,), scale=0.1)
+    dy = synth_tensor(f"bn.dy{shape}", shape, scale=1.0)
+    xd, gd, bd = (t.double().requires_grad_(True) for t in (x, g, b))
+    ref = torch.nn.functional.batch_norm(xd.permute(1, 0, 2), None, None, gd, bd, training=True, eps=1e-5).permute(1, 0, 2)
+    ref.backward(dy.double())
+    xg, gg, bg = (t.to(DEV).requires_grad_(True) for t in (x, g, b))
+    out, mean, var = mgfn_ops.bn_rows_train(xg, gg, bg, 1e-5)
+    out.backward(dy.to(DEV))
+    assert rel_err(out.detach().cpu(), ref.detach()) < 1e-5
+    assert rel_err(mean.cpu(), x.double().mean(dim=(1, 2))) < 1e-5 and rel_err(var.cpu(), x.double().var(dim=(1, 2), unbiased=False)) < 1e-5
+    assert rel_err(xg.grad.cpu(), xd.grad) < 1e-4
+    assert rel_err(gg.grad.cpu(), gd.grad) < 1e-4 and rel_err(bg.grad.cpu(), bd.grad) < 1e-5
