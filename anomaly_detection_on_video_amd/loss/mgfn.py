@@ -1,5 +1,7 @@
-"""`MGFNLoss` with the reference's signature (`/root/reference/src/loss/mgfn.py:7-47`).  On CUDA
-tensors it is the fused HIP loss kernel restricted to its MGFN terms; see loss/base.py's note."""
+"""`MGFNLoss` with the reference's class name and signature (`/root/reference/src/loss/mgfn.py:7-47`), as plain torch ops:
+an API-compatibility module for user code that instantiates the loss classes directly.  The product path does NOT go
+through it: `MGFNForVideoAnomalyDetection.forward` computes all four loss terms with the fused HIP kernels of
+csrc/loss.hip (`mil_ops.mgfn_loss`, forward and backward)."""
 import torch
 from torch import nn
 

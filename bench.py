@@ -57,14 +57,14 @@ def measured_traffic(batch: int):
 
 
 def kernels_sha16() -> str:
-    """Hash of the kernel sources + tuned table: a traffic profile is only as fresh as these."""
-    import glob
+    """Hash of the conv-stack kernel sources + tuned table + plan: a traffic profile is only as fresh as these."""
     import hashlib
 
     h = hashlib.sha256()
     pkg = os.path.join(ROOT, "anomaly_detection_on_video_amd")
-    for path in sorted(glob.glob(os.path.join(pkg, "csrc", "*.hip")) + glob.glob(os.path.join(pkg, "csrc", "*.h")) +
-                       [os.path.join(pkg, "tuned", "gfx950.json"), os.path.join(pkg, "i3d.py"), os.path.join(pkg, "pipeline.py")]):
+    # what decides the conv stack's HBM traffic: its kernels, the tile table and the launch plan
+    for path in [os.path.join(pkg, "csrc", "conv_igemm.hip"), os.path.join(pkg, "csrc", "pool.hip"), os.path.join(pkg, "csrc", "common.h"),
+                 os.path.join(pkg, "tuned", "gfx950.json"), os.path.join(pkg, "i3d.py"), os.path.join(pkg, "ops.py"), os.path.join(pkg, "pipeline.py")]:
         with open(path, "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

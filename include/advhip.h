@@ -125,7 +125,7 @@ int advhip_conv3d_bn_act_strided_f32(const advhip_conv3d_desc* d, const float* x
                                      const float* residual, float* y, int64_t y_batch_stride, void* workspace,
                                      int64_t workspace_bytes, void* stream);
 
-/* The same with the two extra epilogue operands the MGFN scorer's GEMM-shaped layers need (a 1x1 Conv1d over a
+/* The same with the extra epilogue operands the MGFN scorer's GEMM-shaped layers need, all optional (a 1x1 Conv1d over a
  * (C, B*T) activation is this conv on a (1, C, 1, 1, B*T) tensor; src/models/mgfn/modeling_mgfn.py:49-64, 150-205):
  *   y_preact (nullable, y's shape / batch stride): receives the value BEFORE the activation -- z of h = GELU(z), kept for
  *            the backward pass while y gets h (MGFNFeedForward in_conv -> GELU, :53-56);
