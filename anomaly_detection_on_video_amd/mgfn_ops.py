@@ -59,6 +59,22 @@ def _const(n: int, value: float, dev) -> torch.Tensor:
     return _CONST[key]
 
 
+_PACKED: Dict[int, Tuple] = {}
+
+
+def pack_kc_cached(param: torch.Tensor) -> torch.Tensor:
+    """pack_kc of a parameter, re-done only when the parameter has changed (its version counter moves with every
+    optimizer step; inference re-uses the packed copy call after call)."""
+    key = id(param)
+    hit = _PACKED.get(key)
+    stamp = (param.data_ptr(), param._version, tuple(param.shape))
+    if hit is None or hit[0] != stamp:
+        hit = _PACKED[key] = (stamp, pack_kc(param.detach()))
+        if len(_PACKED) > 4096:  # parameters of discarded models
+            _PACKED.clear()
+    return hit[1]
+
+
 def pack_kc(w: torch.Tensor) -> torch.Tensor:
     """(Cout, Cin, k) Conv1d weights -> the kernels' [Cin*k (padded to 32)][Cout] operand."""
     cout, cin, k = w.shape
@@ -113,7 +129,7 @@ class _LinearCN(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual):
         cout, cin, k = weight.shape
-        y = conv_cn(x, pack_kc(weight.detach()), cout, k, shift=bias.detach() if bias is not None else None,
+        y = conv_cn(x, pack_kc_cached(weight), cout, k, shift=bias.detach() if bias is not None else None,
                     residual=residual.detach().contiguous() if residual is not None else None)
         ctx.save_for_backward(x, weight)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
@@ -150,9 +166,9 @@ class _FFNCN(torch.autograd.Function):
     def forward(ctx, xh, x_res, w1, b1, w2, b2):
         hid, dim = w1.shape[0], w1.shape[1]
         need_z = any(ctx.needs_input_grad)
-        out = conv_cn(xh, pack_kc(w1.detach()), hid, 1, shift=b1.detach(), act=ACT_GELU, want_preact=need_z)
+        out = conv_cn(xh, pack_kc_cached(w1), hid, 1, shift=b1.detach(), act=ACT_GELU, want_preact=need_z)
         h, z = out if need_z else (out, None)
-        y = conv_cn(h, pack_kc(w2.detach()), dim, 1, shift=b2.detach(), residual=x_res.detach().contiguous())
+        y = conv_cn(h, pack_kc_cached(w2), dim, 1, shift=b2.detach(), residual=x_res.detach().contiguous())
         if need_z:
             ctx.save_for_backward(xh, z, h, w1, w2)
         return y
@@ -179,18 +195,27 @@ def ffn_cn(xh: torch.Tensor, x_res: torch.Tensor, in_conv: torch.nn.Conv1d, out_
     return _FFNCN.apply(xh.contiguous(), x_res, in_conv.weight, in_conv.bias, out_conv.weight, out_conv.bias)
 
 
+_FOLDED: Dict[int, Tuple] = {}
+
+
 @torch.no_grad()
 def ffn_cn_folded_ln(x: torch.Tensor, norm, in_conv: torch.nn.Conv1d, out_conv: torch.nn.Conv1d) -> torch.Tensor:
     """Inference form of `ffn(x) + x` with the channel LayerNorm folded into the first GEMM: W1.LN(x) = (W1.diag(g)) x_raw
-    * rs - rowsum(W1.diag(g)) * mu * rs + W1.b, statistics per position from one pass over x (advhip_chan_stats_f32)."""
+    * rs - rowsum(W1.diag(g)) * mu * rs + W1.b, statistics per position from one pass over x (advhip_chan_stats_f32).
+    The folded operands are cached until one of the four parameters changes."""
     x = x.contiguous()
     hid, dim = in_conv.weight.shape[0], in_conv.weight.shape[1]
-    w1 = in_conv.weight.view(hid, dim)
-    wg = w1 * norm.g.view(1, dim)
+    params = (in_conv.weight, in_conv.bias, norm.g, norm.b)
+    stamp = tuple((p.data_ptr(), p._version) for p in params)
+    hit = _FOLDED.get(id(in_conv))
+    if hit is None or hit[0] != stamp:
+        w1 = in_conv.weight.view(hid, dim)
+        wg = w1 * norm.g.view(1, dim)
+        hit = _FOLDED[id(in_conv)] = (stamp, pack_kc(wg.view(hid, dim, 1)), (in_conv.bias + w1 @ norm.b.view(dim)).contiguous(), wg.sum(1).contiguous())
+    _, wg_packed, shift, u = hit
     mu, rs = chan_stats(x, norm.eps)
-    shift = in_conv.bias + w1 @ norm.b.view(dim)
-    h = conv_cn(x, pack_kc(wg.view(hid, dim, 1)), hid, 1, shift=shift, act=ACT_GELU, ln=(wg.sum(1).contiguous(), mu, rs))
-    return conv_cn(h, pack_kc(out_conv.weight), dim, 1, shift=out_conv.bias, residual=x)
+    h = conv_cn(x, wg_packed, hid, 1, shift=shift, act=ACT_GELU, ln=(u, mu, rs))
+    return conv_cn(h, pack_kc_cached(out_conv.weight), dim, 1, shift=out_conv.bias, residual=x)
 
 
 # ---- fused element-wise layers (csrc/mgfn.hip) -------------------------------------------------------------------------
