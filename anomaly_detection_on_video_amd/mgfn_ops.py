@@ -17,6 +17,7 @@ kernels' shapes (fewer than 128 channels, Cout % 64 != 0, Cin % 32 != 0) stay on
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -31,13 +32,28 @@ _KTABS: Dict[Tuple, torch.Tensor] = {}
 _CONST: Dict[Tuple, torch.Tensor] = {}
 
 
+MIN_CHANNELS = int(os.environ.get("ADV_MGFN_HIP_MIN_CHANNELS", "64"))
+
+
 def eligible(cin: int, cout: int, x: torch.Tensor) -> bool:
-    return x.is_cuda and x.dtype == torch.float32 and min(cin, cout) >= 128 and cout % 64 == 0 and cin % 32 == 0
+    return x.is_cuda and x.dtype == torch.float32 and min(cin, cout) >= MIN_CHANNELS and cout % 64 == 0 and cin % 32 == 0
+
+
+ALGO_SMALL = _lib.ALGO_DMA2_BASE + _lib.ALGO_IGEMM_64x64  # few output tiles: 64 x 64 tiles (+ split-K inside the launch)
 
 
 def _desc(cin: int, cout: int, k: int, b: int, t: int, act: int) -> ConvDesc:
     # (1, C, 1, b, t) tensor, kernel (1, 1, k), padding (0, 0, k // 2): for k = 1 the caller folds (b, t) into one row
-    return ConvDesc(1, cin, 1, b, t, cout, 1, 1, k, 1, 1, 1, 0, 0, k // 2, act, ALGO, 1)
+    n = b * t
+    tiles128 = -(-n // 128) * (cout // 64)
+    algo, splits = ALGO, 1
+    if tiles128 < 768:  # not enough 128 x 64 tiles for 256 CUs x 3: smaller tiles, and K slices when K is long
+        algo = ALGO_SMALL
+        tiles = -(-n // 64) * (cout // 64)
+        ktiles = -(-(cin * k) // 16)
+        while tiles * splits < 768 and splits < 8 and ktiles // (splits + 1) >= 16:
+            splits += 1
+    return ConvDesc(1, cin, 1, b, t, cout, 1, 1, k, 1, 1, 1, 0, 0, k // 2, act, algo, splits)
 
 
 def _ktab(d: ConvDesc, dev) -> torch.Tensor:
@@ -100,9 +116,14 @@ def conv_cn(x: torch.Tensor, w_packed: torch.Tensor, cout: int, k: int = 1, shif
     for tns in (residual, dact_z):
         if tns is not None and (tuple(tns.shape) != (cout, b, t) or not tns.is_contiguous()):
             raise ValueError("conv_cn: residual / dact_z must be contiguous (Cout, B, T)")
-    check(_lib.load().advhip_conv3d_bn_act_ex_f32(C.byref(d), ptr(x), 0, ptr(w_packed), ptr(_ktab(d, dev)), ptr(_const(cout, 1.0, dev)),
-                                                  ptr(shift if shift is not None else _const(cout, 0.0, dev)), ptr(residual), ptr(y), 0,
-                                                  C.byref(ep), None, 0, stream()), "conv_cn")
+    lib = _lib.load()
+    need = lib.advhip_conv3d_workspace_bytes(C.byref(d)) if d.splits > 1 else 0
+    if need < 0:
+        check(int(need), "conv_cn workspace")
+    ws = ops.workspace(dev, need)
+    check(lib.advhip_conv3d_bn_act_ex_f32(C.byref(d), ptr(x), 0, ptr(w_packed), ptr(_ktab(d, dev)), ptr(_const(cout, 1.0, dev)),
+                                          ptr(shift if shift is not None else _const(cout, 0.0, dev)), ptr(residual), ptr(y), 0,
+                                          C.byref(ep), ptr(ws), need, stream()), "conv_cn")
     return (y, z) if want_preact else y
 
 
