@@ -32,11 +32,16 @@ _KTABS: Dict[Tuple, torch.Tensor] = {}
 _CONST: Dict[Tuple, torch.Tensor] = {}
 
 
-MIN_CHANNELS = int(os.environ.get("ADV_MGFN_HIP_MIN_CHANNELS", "64"))
+# smallest channel count that goes to the HIP GEMMs: inference takes the 64-channel layers too (stage 0, the 2048 -> 64
+# token conv: 2.49 vs 2.84 ms per video); with autograd they stay on torch (their weight-gradient GEMMs are tiny and the
+# k = 3 unfold of the 2048-channel input costs more than it saves: 22.5 vs 22.0 ms per training step)
+MIN_CHANNELS_INFER = int(os.environ.get("ADV_MGFN_HIP_MIN_CHANNELS", "64"))
+MIN_CHANNELS_TRAIN = 128
 
 
 def eligible(cin: int, cout: int, x: torch.Tensor) -> bool:
-    return x.is_cuda and x.dtype == torch.float32 and min(cin, cout) >= MIN_CHANNELS and cout % 64 == 0 and cin % 32 == 0
+    floor = MIN_CHANNELS_TRAIN if torch.is_grad_enabled() else MIN_CHANNELS_INFER
+    return x.is_cuda and x.dtype == torch.float32 and min(cin, cout) >= floor and cout % 64 == 0 and cin % 32 == 0
 
 
 ALGO_SMALL = _lib.ALGO_DMA2_BASE + _lib.ALGO_IGEMM_64x64  # few output tiles: 64 x 64 tiles (+ split-K inside the launch)
