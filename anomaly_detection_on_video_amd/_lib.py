@@ -36,10 +36,13 @@ ALGO_BF16X3_BASE = 128  # + tile id 5 (128x128x32) / 6 (128x64x32): opt-in split
 BF16X3_ALGOS = tuple(ALGO_BF16X3_BASE + a for a in (5, 6))
 ALGO_DMA2_BASE = 160  # + tile id: LDS-DMA kernel, 2-deep ring (less LDS, more resident workgroups)
 DMA2_ALGOS = tuple(ALGO_DMA2_BASE + a for a in (1, 2, 3, 4, 6, 7, 8))
+ALGO_TSPAN_128x64 = 192  # (kt,1,1) convs: 128x64 tile of 2 or 4 frames x flattened spatial positions
 
 
 def algo_tile(algo: int):
     """(BM, BN, BK) of an implicit-GEMM algorithm id."""
+    if algo == ALGO_TSPAN_128x64:
+        return (128, 64, 16)
     if algo >= ALGO_DMA2_BASE:
         algo -= ALGO_DMA2_BASE
     if algo >= ALGO_BF16X3_BASE:

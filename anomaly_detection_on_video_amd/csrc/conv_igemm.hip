@@ -597,7 +597,11 @@ enum : int {
   EPI_TPOOL = 2,    // + MaxPool3d k(2,1,1) s(2,1,1): brick 2(t) x BM/2 flattened (h,w) of a 1x1x1 conv; exact, no halo
   EPI_POOL233 = 3,  // + ReLU + MaxPool3d k(2,3,3) s(2,2,2) p0: brick 2(t) x 4(h) x BM/8(w); per-brick maxima of every pooling
                     //   window the brick touches go to a partial tensor, stem_pool_merge_kernel maxes the 1/2/4 partials
+  EPI_TSPAN2 = 4,   // plain output, m-tiles that span T: brick 2(t) x BM/2 flattened (h,w) of a (kt,1,1) conv -- the kt temporal taps
+  EPI_TSPAN4 = 5,   //   of a tile read the SAME activation rows (shifted by one plane), so they hit L1/L2 instead of being fetched by
+                    //   three m-tiles that run ~47 tiles apart; 4(t) x BM/4 for T = 4
 };
+constexpr int brick_t(int epi) { return epi == EPI_TSPAN4 ? 4 : 2; }
 
 // ---- pooling epilogues on brick-ordered tiles (128 x 64 tile, 2 x 2 waves) ----------------------------------------------
 // Wave (wm, wn) holds t plane wm of the brick (64 positions: BH rows of BW outputs) for 32 channels; accumulator element
@@ -613,11 +617,40 @@ __device__ __forceinline__ void brick_epilogue(const ConvArgs& a, f32x4 (&acc)[B
                                                int tid) {
   constexpr int FM = BM / 32, FN = BN / 32, RS = BM + 4, CH = BN / FN;  // CH channels per pass
   static_assert(FM == 4 && FN == 2, "128 x 64 tile");
-  constexpr int BH = EPI == EPI_POOL233 ? 4 : 1, BW = BM / (2 * BH);
+  constexpr int BT = brick_t(EPI), BH = EPI == EPI_POOL233 ? 4 : 1, BW = BM / (BT * BH);
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lg = lane >> 4;
   const int c_w = wn * 16 + li;  // this lane's channel row of the pass
-  if constexpr (EPI == EPI_TPOOL) {
+  if constexpr (EPI == EPI_TSPAN2 || EPI == EPI_TSPAN4) {
+    // un-pooled output of a brick-ordered tile: thread = one position (dt, p) of the brick, 16 channels of the pass
+#pragma unroll
+    for (int jn = 0; jn < FN; ++jn) {
+      const int n_w = n0 + 2 * c_w + jn;
+      const float sc = a.scale[n_w], sf = a.shift[n_w];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<float4*>(&smem[c_w * RS + wm * 64 + 16 * lg + 4 * r]) =
+            make_float4(acc[0][jn][r] * sc + sf, acc[1][jn][r] * sc + sf, acc[2][jn][r] * sc + sf, acc[3][jn][r] * sc + sf);
+      __syncthreads();
+      // 256 threads = 2 channel halves x 128 positions: consecutive lanes run along the BW positions of one t plane
+      const int pos = tid % BM, ch0 = tid / BM;           // ch0 in {0, 1}
+      const int dt = pos / BW, pw = pos % BW;
+      const int ot = bk_t * BT + dt, ow = bk_w * BW + pw;
+      if (ot < a.To && ow < a.Wo) {
+#pragma unroll
+        for (int i = 0; i < CH / 2; ++i) {
+          const int c = ch0 + 2 * i;
+          const int n = n0 + 2 * c + jn;
+          float v = smem[c * RS + pos];
+          const size_t o = ((size_t)bk_b * a.Cout + n) * a.THWo + (size_t)ot * a.HWo + ow;
+          if (a.res) v += a.res[o];
+          if (a.relu) v = act_apply(a.relu, v);
+          a.y[(size_t)bk_b * a.y_bstride + (size_t)n * a.THWo + (size_t)ot * a.HWo + ow] = v;
+        }
+      }
+      __syncthreads();
+    }
+  } else if constexpr (EPI == EPI_TPOOL) {
 #pragma unroll
     for (int jn = 0; jn < FN; ++jn) {
       const int n_w = n0 + 2 * c_w + jn;
@@ -850,7 +883,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   constexpr int SMEM0 = RING > Cfg::ST_FLOATS ? RING : Cfg::ST_FLOATS;
   constexpr int SMEM = SMEM0 > BRICK_FLOATS ? SMEM0 : BRICK_FLOATS;
   static_assert(EPI == EPI_STD || (BM == 128 && BN == 64), "pooling epilogues: 128 x 64 tile (wave row = one t plane of the brick)");
-  constexpr int BRICK_H = EPI == EPI_POOL233 ? 4 : 1, BRICK_W = BM / (2 * BRICK_H);
+  constexpr int BRICK_T = brick_t(EPI), BRICK_H = EPI == EPI_POOL233 ? 4 : 1, BRICK_W = BM / (BRICK_T * BRICK_H);
 
   __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
@@ -903,7 +936,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
     bk_h = (int)a.dNbw.div((unsigned)r2);
     bk_w = r2 - bk_h * a.nbw;
     pb = bk_b;
-    pot = bk_t * 2 + ml / (BRICK_H * BRICK_W);
+    pot = bk_t * BRICK_T + ml / (BRICK_H * BRICK_W);
     poh = bk_h * BRICK_H + (ml / BRICK_W) % BRICK_H;
     pow_ = bk_w * BRICK_W + ml % BRICK_W;
     pvalid = pot < a.To && poh < a.Ho && pow_ < a.Wo;
@@ -1552,6 +1585,7 @@ struct Choice {
 };
 
 static void tile_of(int algo, int* BM, int* BN, int* BK) {
+  if (algo == ADVHIP_ALGO_TSPAN_128x64) { *BM = 128; *BN = 64; *BK = 16; return; }
   if (algo >= ADVHIP_ALGO_DMA2_BASE) algo -= ADVHIP_ALGO_DMA2_BASE;
   if (algo >= ADVHIP_ALGO_BF16X3_BASE) algo -= ADVHIP_ALGO_BF16X3_BASE;
   if (algo >= ADVHIP_ALGO_DMA4_BASE) algo -= ADVHIP_ALGO_DMA4_BASE;
@@ -1566,6 +1600,7 @@ static void tile_of(int algo, int* BM, int* BN, int* BK) {
 // Which (family, tile) ids have a kernel in this library.  Ids inside a family's range without an instantiation
 // (e.g. DMA_BASE + 5) are rejected up front: a launch switch that fell through would return OK with y unwritten.
 static bool instantiated(int algo) {
+  if (algo == ADVHIP_ALGO_TSPAN_128x64) return true;
   auto tile_in = [](int t, unsigned mask) { return t >= 1 && t <= 8 && ((mask >> t) & 1u); };
   constexpr unsigned ALL = 0x1FEu, NO5 = ALL & ~(1u << 5);
   if (algo >= ADVHIP_ALGO_DMA2_BASE) return tile_in(algo - ADVHIP_ALGO_DMA2_BASE, NO5);
@@ -1644,6 +1679,10 @@ static SplitLayout split_layout(const advhip_conv3d_desc* d, const Geometry& g, 
   return {(tiles * 4 + 255) / 256 * 256, tiles * c.splits * BM * BN * (int64_t)sizeof(float)};
 }
 }  // namespace advhip
+
+namespace advhip {
+static void set_bricks(ConvArgs& a, int nbt, int nbh, int nbw);  // defined with the pooling launchers below
+}
 
 extern "C" int64_t advhip_conv3d_workspace_bytes(const advhip_conv3d_desc* d) {
   if (validate(d)) return -1;
@@ -1766,6 +1805,19 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
   a.tiles_n = d->Cout / BN;
   a.dTilesN = FastDiv::make((unsigned)a.tiles_n);
   a.dSplits = FastDiv::make((unsigned)c.splits);
+  int tspan_bt = 0;
+  if (c.algo == ADVHIP_ALGO_TSPAN_128x64) {
+    // m-tiles that span T: (kt,1,1) stride-1 "same" convs only; the spatial plane is presented as one flattened row
+    ADVHIP_REQUIRE(d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 && 2 * d->pt + 1 == d->kt,
+                   "conv3d: ADVHIP_ALGO_TSPAN needs a (kt,1,1) stride-1 conv with padding kt/2 (k=%d,%d,%d)", d->kt, d->kh, d->kw);
+    ADVHIP_REQUIRE(c.splits == 1 && g.To % 2 == 0 && y_preact == nullptr && dact_z == nullptr && !ln,
+                   "conv3d: ADVHIP_ALGO_TSPAN runs unsplit on an even number of frames (T=%d, splits=%d) without the MGFN epilogue operands", g.To, c.splits);
+    tspan_bt = g.To % 4 == 0 ? 4 : 2;
+    a.H = 1; a.W = d->H * d->W; a.Ho = 1; a.Wo = a.HWo;
+    a.kh_ = 1; a.kw_ = 1;
+    set_bricks(a, g.To / tspan_bt, 1, (a.Wo + 128 / tspan_bt - 1) / (128 / tspan_bt));
+    a.Tp = 0;
+  }
   dim3 grid((unsigned)(a.tiles_m * a.tiles_n * c.splits));
   hipStream_t st = (hipStream_t)stream;
   if (a.cnt != nullptr) {  // arrival counters start every launch at zero (a memset node: graph-capturable, replayed first)
@@ -1802,6 +1854,10 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
     else hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BN_, true>), grid, dim3(256), 0, st, a);                   \
     break;
   switch (c.algo) {
+    case ADVHIP_ALGO_TSPAN_128x64:
+      if (tspan_bt == 4) hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, true, 2, EPI_TSPAN4>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, true, 2, EPI_TSPAN2>), grid, dim3(256), 0, st, a);
+      break;
     ADVHIP_DMA2_CASE(ADVHIP_ALGO_IGEMM_128x128, 128, 128, 16)
     ADVHIP_DMA2_CASE(ADVHIP_ALGO_IGEMM_128x64, 128, 64, 16)
     ADVHIP_DMA2_CASE(ADVHIP_ALGO_IGEMM_64x64, 64, 64, 16)

@@ -56,6 +56,10 @@ extern "C" {
 /* + tile id 1..4, 6..8: the LDS-DMA kernel with a 2-deep ring (one k-tile in flight): 16 KiB of LDS per 64x64x16
  * workgroup instead of 24 -> 8 resident workgroups per CU instead of 6 */
 #define ADVHIP_ALGO_DMA2_BASE 160
+/* the 2-deep LDS-DMA kernel, 128x64x16 tile, with m-tiles that span T (2 or 4 frames x 64 / 32 flattened spatial positions)
+ * for (kt,1,1) stride-1 "same" convs: the temporal taps of a tile re-read the same activation rows from L1/L2 instead of
+ * three far-apart tiles fetching them from HBM.  Unsplit; T even. */
+#define ADVHIP_ALGO_TSPAN_128x64 192
 
 typedef struct advhip_conv3d_desc {
   int32_t B, Cin, T, H, W;    /* input  (B, Cin, T, H, W) */

@@ -198,6 +198,53 @@ def test_conv_split_k_vs_oracle(case, algo, splits):
     assert torch.equal(out, out2)
 
 
+TSPAN_CASES = [c for c in CONV_CASES if c[3][1:] == (1, 1) and c[4] == (1, 1, 1) and c[6][1] % 2 == 0] + [
+    ("tspan.t6", 64, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 6, 9, 10)),     # T = 6: two-frame bricks, three per column
+    ("tspan.t8.k5", 32, 64, (5, 1, 1), (1, 1, 1), (2, 0, 0), (1, 8, 7, 5)),    # five temporal taps, four-frame bricks
+    ("tspan.55", 256, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 4, 55, 55)),    # layer1.x.conv1 at its real plane size
+]
+
+
+@pytest.mark.parametrize("case", TSPAN_CASES, ids=[c[0] for c in TSPAN_CASES])
+def test_conv_tspan_tiles_vs_oracle(case):
+    """ADVHIP_ALGO_TSPAN_128x64: (kt,1,1) convs on m-tiles that span T (brick-ordered rows, same MFMA loop).  Same fp32
+    k-order as the plain 128x64 tile, so bit-identical to it, and within 2e-5 of the oracle."""
+    from anomaly_detection_on_video_amd import _lib, ops
+    from oracle import i3d_oracle
+
+    name, cin, cout, k, s, p, bthw = case
+    x, wt, g, be, mu, var, res = _conv_case(*case)
+    dev = _dev()
+    pc = ops.pack_conv(wt.to(dev), g.to(dev), be.to(dev), mu.to(dev), var.to(dev), 1e-5, s, p, name=name)
+    for use_res, relu in ((False, True), (True, True), (True, False)):
+        ref = i3d_oracle.conv_bn_act(x, wt, g, be, mu, var, s, p, res if use_res else None, relu)
+        out = ops.conv3d_bn_act(x.to(dev), pc, relu=relu, residual=res.to(dev) if use_res else None, algo=_lib.ALGO_TSPAN_128x64)
+        assert rel_err(out.cpu(), ref) < TIGHT, f"{name} res={use_res} relu={relu}"
+        plain = ops.conv3d_bn_act(x.to(dev), pc, relu=relu, residual=res.to(dev) if use_res else None, algo=162)
+        assert torch.equal(out, plain)
+    # into a channel slice of a wider buffer
+    wide = torch.full((bthw[0], cout + 64) + tuple(out.shape[2:]), 9.0, device=dev)
+    ops.conv3d_bn_act(x.to(dev), pc, relu=False, residual=res.to(dev), out=wide[:, 64:], algo=_lib.ALGO_TSPAN_128x64)
+    assert torch.equal(wide[:, 64:], out) and (wide[:, :64] == 9.0).all()
+
+
+def test_conv_tspan_rejects_what_it_cannot_run():
+    from anomaly_detection_on_video_amd import _lib, ops
+
+    dev = _dev()
+    for name in ("l1.conv2", "l2.ds.s2"):  # spatial window / strided
+        case = next(c for c in CONV_CASES if c[0] == name)
+        x, wt, g, be, mu, var, _res = _conv_case(*case)
+        pc = ops.pack_conv(wt.to(dev), g.to(dev), be.to(dev), mu.to(dev), var.to(dev), 1e-5, case[4], case[5], name=name)
+        with pytest.raises(_lib.HipExtensionError, match="TSPAN"):
+            ops.conv3d_bn_act(x.to(dev), pc, algo=_lib.ALGO_TSPAN_128x64)
+    case = ("odd.t", 64, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 3, 5, 5))
+    x, wt, g, be, mu, var, _res = _conv_case(*case)
+    pc = ops.pack_conv(wt.to(dev), g.to(dev), be.to(dev), mu.to(dev), var.to(dev), 1e-5, case[4], case[5], name="odd.t")
+    with pytest.raises(_lib.HipExtensionError, match="even number of frames"):
+        ops.conv3d_bn_act(x.to(dev), pc, algo=_lib.ALGO_TSPAN_128x64)
+
+
 @pytest.mark.parametrize("shape,k,s", [
     ((2, 64, 8, 28, 30), (2, 3, 3), (2, 2, 2)),   # maxpool1 (odd output extents)
     ((2, 256, 4, 11, 13), (2, 1, 1), (2, 1, 1)),  # maxpool2
