@@ -27,6 +27,8 @@ def table() -> Dict[str, Tuple[int, int]]:
 
 def lookup(key: str, default: Tuple[int, int]) -> Tuple[int, int]:
     algo, splits = table().get(key, default)
+    if algo == 192 and os.environ.get("ADV_NO_TSPAN") == "1":  # experiment knob: the T-spanning tiles back on the plain 128x64 tile
+        algo = 162
     cap = int(os.environ.get("ADV_MAX_SPLITS", "0"))  # experiment knob: cap the split-K factor of tuned entries
     if cap > 0 and splits > cap:
         splits = cap
