@@ -76,6 +76,7 @@ struct ConvArgs {
   int THWo, HWo, HW, THW;
   int tiles_m, tiles_n;
   int relu, vw;       // relu: activation code 0 none, 1 ReLU, 2 GELU (erf)
+  int a16;            // 1x1x1 stride-1 conv on 16-byte aligned rows: the A rows go to LDS as 16-byte LDS-DMA pieces (2-deep ring kernels)
   float* y2;          // nullable: the pre-activation value (after scale/shift/residual), y's addressing -- saved for backward
   const float* dact;  // nullable: z of a GELU, y's addressing (dense): the result is multiplied by gelu'(z) (fused GELU backward)
   // nullable LayerNorm fold (1x1x1 convs over a (C, positions) activation): conv(W.diag(g), x_raw) -> W.LN(x) - W.b:
@@ -956,6 +957,30 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   constexpr int RPW = 64 / LPRB;
   const unsigned wvoff = (unsigned)((lane / LPRB) * a.Cout + (lane % LPRB) * 4) * 4u;
   const int a_wave_col = (wave % (BM / 64)) * 64;  // which 64-float piece of an A row this wave fills
+  // 1x1x1 stride-1 convs (row k of A = channel k's positions, contiguous and 16-byte aligned: a.a16): the A tile goes to LDS
+  // in 16-byte pieces -- one wave-instruction = 1 KiB = 256/BM whole k-rows -- instead of one 4-byte piece per row and
+  // wave: 4x fewer VMEM issues per tile (the LDS-DMA issue of the 4-byte form costs ~10 % of such a kernel,
+  // profiles/r01_pmc_notes.md).  Tap offsets are linear in k here (k * THW), so no table is read.  2-deep ring only: its
+  // waits are vmcnt(0) whatever the number of pieces.
+  constexpr bool CAN16 = !CHECK && NS == 2 && EPI == EPI_STD;
+  constexpr int RPI16 = 256 / BM, LA16 = BK * BM / 1024;
+  static_assert(LA16 >= 1, "tile too small for 16-byte A pieces");
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int A16_BYTES = 16;  // (the host pass only parses this body; see gemm_kk_dma_kernel)
+#else
+  constexpr int A16_BYTES = 4;
+#endif
+  const bool a16 = CAN16 && a.a16 != 0;
+  unsigned vbase16 = OOB;
+  if constexpr (CAN16) {
+    if (a16) {
+      const int m4 = m0 + (lane % (BM / 4)) * 4;
+      if (m4 < a.M) {
+        const int b4 = (int)a.dTHWo.div((unsigned)m4);
+        vbase16 = (unsigned)(b4 * a.x_bstride + (m4 - b4 * a.THWo) + (lane / (BM / 4)) * a.THW) * 4u;
+      }
+    }
+  }
 
   // wave group kr fills k-rows [kr*LA, (kr+1)*LA) of a tile: its table entries are contiguous.
   // (issue_part can also issue a 1/nparts slice of a tile's loads; the product issues whole tiles.)
@@ -963,13 +988,26 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   auto issue_part = [&](int k0, int stage, int part, int nparts) {
     float* As = smem + stage * D::STAGE;
     float* Bs = As + BK * BM;
+    bool done16 = false;
+    if constexpr (CAN16) {
+      if (a16) {
 #pragma unroll
-    for (int j = 0; j < LA; ++j) {
-      if (j * nparts / LA != part) continue;
-      const int krow = kr * LA + j;
-      unsigned voff = vbase;
-      if constexpr (CHECK) voff = ((vmask & (unsigned)ent[2 * j + 1]) == (unsigned)ent[2 * j + 1]) ? vbase : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(As + krow * BM + a_wave_col), 4, voff, ent[2 * j], 0, 0);
+        for (int q = 0; q < LA16; ++q) {
+          const int g = wave * LA16 + q;  // piece g = k-rows [g * RPI16, (g + 1) * RPI16) of the tile
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(As + g * RPI16 * BM), A16_BYTES, vbase16, (k0 + g * RPI16) * a.THW * 4, 0, 0);
+        }
+        done16 = true;
+      }
+    }
+    if (!done16) {
+#pragma unroll
+      for (int j = 0; j < LA; ++j) {
+        if (j * nparts / LA != part) continue;
+        const int krow = kr * LA + j;
+        unsigned voff = vbase;
+        if constexpr (CHECK) voff = ((vmask & (unsigned)ent[2 * j + 1]) == (unsigned)ent[2 * j + 1]) ? vbase : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(As + krow * BM + a_wave_col), 4, voff, ent[2 * j], 0, 0);
+      }
     }
 #pragma unroll
     for (int j = 0; j < LB; ++j) {
@@ -979,7 +1017,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
     }
   };
   auto issue_tile = [&](int k0, int stage) {
-    sload_entries<LA>(ktab2, (k0 + kr * LA) * 8, ent);
+    if (!a16) sload_entries<LA>(ktab2, (k0 + kr * LA) * 8, ent);
     issue_part(k0, stage, 0, 1);
   };
 
@@ -1053,7 +1091,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");  // all waves' parts of tile kt are in LDS; stage (kt-1)%NS is free
     const bool pre = kt + NS - 1 < kt1;
-    if (pre) sload_entries<LA>(ktab2, ((kt + NS - 1) * BK + kr * LA) * 8, ent);
+    if (pre && !a16) sload_entries<LA>(ktab2, ((kt + NS - 1) * BK + kr * LA) * 8, ent);
     compute(pre, stage, (kt + NS - 1) * BK, stage == 0 ? NS - 1 : stage - 1);
     stage = stage == NS - 1 ? 0 : stage + 1;
   }
@@ -1828,6 +1866,8 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
   if (BK == 32) ADVHIP_REQUIRE(g.Kpad % 32 == 0, "conv3d: BK=32 variants need K padded to 32 (K=%d)", g.K);
   // every tap of every output position inside the input: no validity mask needed
   const bool nocheck = d->kt == 1 && d->kh == 1 && d->kw == 1 && d->pt == 0 && d->ph == 0 && d->pw == 0 && g.K == g.Kpad;
+  // ... and rows of 4 consecutive positions contiguous and 16-byte aligned in x: 16-byte LDS-DMA pieces for A
+  a.a16 = (nocheck && d->st == 1 && d->sh == 1 && d->sw == 1 && a.THW % 4 == 0 && xbs % 4 == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0;
 #define ADVHIP_FAST_CASE(ID, BM_, BN_, BK_)                                                                         \
   case ADVHIP_ALGO_FAST_BASE + ID:                                                                                  \
     if (nocheck) hipLaunchKernelGGL((conv3d_igemm_fast_kernel<BM_, BN_, BK_, false>), grid, dim3(256), 0, st, a);   \
@@ -1937,6 +1977,7 @@ static int fill_pool_args(ConvArgs& a, const advhip_conv3d_desc* d, const Geomet
   a.HW = d->H * d->W; a.THW = d->T * a.HW;
   a.relu = d->relu;
   a.vw = 1;
+  a.a16 = 0;
   a.dTHWo = FastDiv::make((unsigned)a.THWo); a.dHWo = FastDiv::make((unsigned)a.HWo); a.dWo = FastDiv::make((unsigned)a.Wo);
   a.kt_ = d->kt; a.kh_ = d->kh; a.kw_ = d->kw;
   a.pad_off = d->pt * d->H * d->W + d->ph * d->W + d->pw;

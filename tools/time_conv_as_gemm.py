@@ -39,6 +39,13 @@ def main():
                 out.append(f"a{algo}:err")
         tb = t(lambda: torch.matmul(W.view(o, c), X.view(c, N)))
         print(f"o={o} c={c}: " + " ".join(out) + f" | torch {fl / tb:.0f} TF")
+        # the same GEMMs on an x that is only 4-byte aligned: the 16-byte A pieces are off (4-byte LDS-DMA form)
+        Xm = torch.empty(c * N + 4, device=dev)[1 : 1 + c * N].view(1, c, 1, 1, N).copy_(X)
+        out = []
+        for algo in (163, 164, 162, 161):
+            ms = t(lambda: ops.conv3d_bn_act(Xm, pc, relu=False, algo=algo, splits=1))
+            out.append(f"a{algo}:{fl / ms:.0f}")
+        print(f"   4-byte A pieces: " + " ".join(out))
 
 
 if __name__ == "__main__":
