@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -89,11 +90,12 @@ def pack_kc_cached(param: torch.Tensor) -> torch.Tensor:
     key = id(param)
     hit = _PACKED.get(key)
     stamp = (param.data_ptr(), param._version, tuple(param.shape))
-    if hit is None or hit[0] != stamp:
-        hit = _PACKED[key] = (stamp, pack_kc(param.detach()))
-        if len(_PACKED) > 4096:  # parameters of discarded models
-            _PACKED.clear()
-    return hit[1]
+    if hit is None or hit[0]() is not param or hit[1] != stamp:  # (ids are re-used once a tensor is gone: check it is the same object)
+        if len(_PACKED) > 1024:
+            for k in [k for k, v in _PACKED.items() if v[0]() is None]:  # parameters of discarded models
+                del _PACKED[k]
+        hit = _PACKED[key] = (weakref.ref(param), stamp, pack_kc(param.detach()))
+    return hit[2]
 
 
 def pack_kc(w: torch.Tensor) -> torch.Tensor:
@@ -234,11 +236,15 @@ def ffn_cn_folded_ln(x: torch.Tensor, norm, in_conv: torch.nn.Conv1d, out_conv: 
     params = (in_conv.weight, in_conv.bias, norm.g, norm.b)
     stamp = tuple((p.data_ptr(), p._version) for p in params)
     hit = _FOLDED.get(id(in_conv))
-    if hit is None or hit[0] != stamp:
+    if hit is None or hit[0]() is not in_conv or hit[1] != stamp:
+        if len(_FOLDED) > 256:
+            for k in [k for k, v in _FOLDED.items() if v[0]() is None]:
+                del _FOLDED[k]
         w1 = in_conv.weight.view(hid, dim)
         wg = w1 * norm.g.view(1, dim)
-        hit = _FOLDED[id(in_conv)] = (stamp, pack_kc(wg.view(hid, dim, 1)), (in_conv.bias + w1 @ norm.b.view(dim)).contiguous(), wg.sum(1).contiguous())
-    _, wg_packed, shift, u = hit
+        hit = _FOLDED[id(in_conv)] = (weakref.ref(in_conv), stamp, pack_kc(wg.view(hid, dim, 1)),
+                                      (in_conv.bias + w1 @ norm.b.view(dim)).contiguous(), wg.sum(1).contiguous())
+    _, _, wg_packed, shift, u = hit
     mu, rs = chan_stats(x, norm.eps)
     h = conv_cn(x, wg_packed, hid, 1, shift=shift, act=ACT_GELU, ln=(u, mu, rs))
     return conv_cn(h, pack_kc_cached(out_conv.weight), dim, 1, shift=out_conv.bias, residual=x)
