@@ -369,7 +369,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, splits: int = 0) -> torch.Tensor:
     N = b.shape[0]
     if splits <= 0:
         tiles = -(-M // 64) * -(-N // 64)
-        splits = max(1, min(8, 1024 // max(tiles, 1), K // 256))
+        splits = max(1, min(64, 1024 // max(tiles, 1), K // 256))  # few output tiles (128-channel layers): many K slices
     out = torch.empty((splits, M, N), device=a.device, dtype=torch.float32)
     check(_lib.load().advhip_gemm_nt_f32(ptr(a), ptr(b), ptr(out), M, N, K, a.stride(0), b.stride(0), N, splits, M * N, stream()), "gemm_nt")
     return out[0] if splits == 1 else out.sum(0)
