@@ -101,6 +101,15 @@ struct ConvArgs {
   unsigned x_bytes;   // buffer range of x (plus pad_off*4)
   unsigned w_bytes;   // buffer range of the packed weights (LDS-DMA kernel)
   FastDiv dTHWo, dHWo, dWo, dTilesN, dSplits;
+  // uint8 frame input (stem + maxpool1 kernel, U8 = true): x = resized uint8 frames (F, FH, FW, Cin); sample b of the launch is
+  // crop-clip u8_first + b = (clip, crop) of torchvision's TenCrop order (4 corners, centre, then the same five mirrored);
+  // T / H / W above are the clip-local extents (frames per clip, crop size) the tap masks are taken against
+  int u8_first, u8_FH, u8_FW;
+  int u8_ctop, u8_cleft;    // top / left of the centre crop (round-half-to-even, as torchvision)
+  float in_mean, in_std;    // the operand is (pixel - in_mean); 1 / in_std goes into the BN scale
+  const int2* ktab_u8;      // [2][Kpad] {byte offset, tap bits}: as stored, and mirrored along w
+  const int* pad_cls;       // {nt, nh, nw, 0}, class of every output t / h / w (which taps fall outside the clip), class masks
+  const float* pad_corr;    // [nt][nh][nw][Cout]: in_mean * (sum of the weights of the taps outside) -- a zero byte is -in_mean, not 0
 };
 
 template <int VW>
@@ -612,7 +621,7 @@ constexpr int brick_t(int epi) { return epi == EPI_TSPAN4 ? 4 : 2; }
 // >= 0 after ReLU, so 0 is neutral for the maxima), then the 256 threads pool from LDS with coalesced global accesses.
 constexpr int POOL_SLOTS = 27;  // per brick and channel: 3 row slots x 9 column slots (see brick_epilogue, EPI_POOL233)
 
-template <int BM, int BN, int BK, int EPI>
+template <int BM, int BN, int BK, int EPI, bool U8 = false>
 __device__ __forceinline__ void brick_epilogue(const ConvArgs& a, f32x4 (&acc)[BM / 32][BN / 32], float* smem, int tile_m,
                                                int tile_n, int n0, int bk_b, int bk_t, int bk_h, int bk_w, int wave, int lane,
                                                int tid) {
@@ -701,12 +710,43 @@ __device__ __forceinline__ void brick_epilogue(const ConvArgs& a, f32x4 (&acc)[B
 #pragma unroll
     for (int jn = 0; jn < FN; ++jn) {
       const int n_w = n0 + 2 * c_w + jn;
-      const float sc = a.scale[n_w], sf = a.shift[n_w];
+      float sc = a.scale[n_w];
+      const float sf = a.shift[n_w];
       float v[16];
+      if constexpr (U8) {
+        // the operand was (pixel - mean): 1 / std belongs to the scale, and a tap outside the clip read as byte 0 = -mean
+        // instead of 0 -- add mean * (sum of this channel's weights over those taps), tabulated per border class
+        sc = sc / a.in_std;
+        const int* cls = a.pad_cls;
+        const int nh = cls[1], nw = cls[2];
+        const int* tcls = cls + 4;
+        const int* hcls = tcls + a.To;
+        const int* wcls = hcls + a.Ho;
+        const int tc = tcls[ot < a.To ? ot : a.To - 1], hc = hcls[oh < a.Ho ? oh : a.Ho - 1];
+        const float* cr = a.pad_corr + (size_t)((tc * nh + hc) * nw) * a.Cout + n_w;
+        const int ow0 = bk_w * BW, owl = a.Wo - 1;
+        const int wc0 = wcls[ow0 < owl ? ow0 : owl], wc1 = wcls[ow0 + 15 < owl ? ow0 + 15 : owl];
+        if (wc0 == wc1) {  // (classes are runs along w: equal at both ends = one class for the whole brick row)
+          const float c0 = cr[(size_t)wc0 * a.Cout];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+          for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[4 * r + i] = fmaxf(acc[i][jn][r] * sc + sf, 0.f);
+            for (int i = 0; i < 4; ++i) v[4 * r + i] = fmaxf((acc[i][jn][r] + c0) * sc + sf, 0.f);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int ow = ow0 + 4 * r + i;
+              v[4 * r + i] = fmaxf((acc[i][jn][r] + cr[(size_t)wcls[ow < owl ? ow : owl] * a.Cout]) * sc + sf, 0.f);
+            }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[4 * r + i] = fmaxf(acc[i][jn][r] * sc + sf, 0.f);
+      }
       if (!inside) {  // positions outside the tensor count as 0: neutral for maxima of post-ReLU values
 #pragma unroll
         for (int w = 0; w < 16; ++w) v[w] = (row_ok && w < wlim) ? v[w] : 0.f;
@@ -870,7 +910,7 @@ constexpr int dma_waves_per_simd() {
   return by_lds > 8 ? 8 : (by_lds < 1 ? 1 : by_lds);
 }
 
-template <int BM, int BN, int BK, bool CHECK, int NS = 3, int EPI = EPI_STD>
+template <int BM, int BN, int BK, bool CHECK, int NS = 3, int EPI = EPI_STD, bool U8 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dma_waves_per_simd<BM, BN, BK, NS>(), 8)))
 void conv3d_igemm_dma_kernel(const ConvArgs a) {
   using Cfg = IgemmCfg<BM, BN, BK>;
@@ -884,6 +924,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   constexpr int SMEM0 = RING > Cfg::ST_FLOATS ? RING : Cfg::ST_FLOATS;
   constexpr int SMEM = SMEM0 > BRICK_FLOATS ? SMEM0 : BRICK_FLOATS;
   static_assert(EPI == EPI_STD || (BM == 128 && BN == 64), "pooling epilogues: 128 x 64 tile (wave row = one t plane of the brick)");
+  static_assert(!U8 || (EPI == EPI_POOL233 && CHECK), "uint8 frame input: the stem + maxpool1 form (an m-tile lies in one crop)");
   constexpr int BRICK_T = brick_t(EPI), BRICK_H = EPI == EPI_POOL233 ? 4 : 1, BRICK_W = BM / (BRICK_T * BRICK_H);
 
   __shared__ __attribute__((aligned(16))) float smem[SMEM];
@@ -942,16 +983,33 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
     pow_ = bk_w * BRICK_W + ml % BRICK_W;
     pvalid = pot < a.To && poh < a.Ho && pow_ < a.Wo;
   }
+  int u8_flip = 0;
   if (pvalid) {
     const int it0 = pot * a.st - a.pt, ih0 = poh * a.sh - a.ph, iw0 = pow_ * a.sw - a.pw;
-    vbase = (unsigned)(pb * a.x_bstride + it0 * a.HW + ih0 * a.W + iw0 + a.pad_off) * 4u;
+    if constexpr (U8) {
+      // byte offset of the window origin in the frames tensor (F, FH, FW, C): the crop's corner, then the clip-local
+      // coordinates; a mirrored crop walks its source columns backwards (its table holds (kw-1-dw) * C, see build_ktab_u8)
+      const int bg = a.u8_first + bk_b, clip = bg / 10, crop = bg - clip * 10, j = crop >= 5 ? crop - 5 : crop;
+      u8_flip = crop >= 5;
+      const int top = j == 4 ? a.u8_ctop : ((j >> 1) ? a.u8_FH - a.H : 0), left = j == 4 ? a.u8_cleft : ((j & 1) ? a.u8_FW - a.W : 0);
+      const int FWC = a.u8_FW * a.Cin, FHWC = a.u8_FH * FWC;
+      // (mirrored crops are five_crop(hflip(frame)): column c of such a crop is source column FW - 1 - (left + c))
+      const int col = u8_flip ? a.u8_FW - 1 - left - iw0 - (a.kw_ - 1) : left + iw0;
+      vbase = (unsigned)((clip * a.T + it0) * FHWC + (top + ih0) * FWC + col * a.Cin + a.pad_off);
+    } else {
+      vbase = (unsigned)(pb * a.x_bstride + it0 * a.HW + ih0 * a.W + iw0 + a.pad_off) * 4u;
+    }
     if constexpr (CHECK) {
       vmask = tap_bits(it0, a.kt_, a.T) | (tap_bits(ih0, a.kh_, a.H) << 10) | (tap_bits(iw0, a.kw_, a.W) << 20);
     }
   }
-  const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) - a.pad_off, 0, a.x_bytes, 0x00020000);
+  const auto rx = U8 ? __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(const_cast<float*>(a.x)) - a.pad_off, 0, a.x_bytes, 0x00020000)
+                     : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) - a.pad_off, 0, a.x_bytes, 0x00020000);
   const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
-  const int2* __restrict__ ktab2 = reinterpret_cast<const int2*>(a.ktab + a.Kpad);
+  // (the brick's crop, hence the table, is the same for the whole workgroup: keep the pointer scalar for the s_loads)
+  const int2* __restrict__ ktab2 = U8 ? a.ktab_u8 + (size_t)__builtin_amdgcn_readfirstlane((bk_b + a.u8_first) % 10 >= 5 ? a.Kpad : 0)
+                                      : reinterpret_cast<const int2*>(a.ktab + a.Kpad);
+  constexpr int A_BYTES = U8 ? 1 : 4;  // uint8 input: `buffer_load_ubyte ... lds` puts the zero-extended byte in the lane's LDS dword
   // B rows: a wave's 64 lanes x 16 B cover RPW consecutive k-rows of the [BK][BN] tile
   constexpr int LPRB = BN / 4;
   constexpr int RPW = 64 / LPRB;
@@ -1006,7 +1064,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
         const int krow = kr * LA + j;
         unsigned voff = vbase;
         if constexpr (CHECK) voff = ((vmask & (unsigned)ent[2 * j + 1]) == (unsigned)ent[2 * j + 1]) ? vbase : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(As + krow * BM + a_wave_col), 4, voff, ent[2 * j], 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(As + krow * BM + a_wave_col), A_BYTES, voff, ent[2 * j], 0, 0);
       }
     }
 #pragma unroll
@@ -1066,6 +1124,16 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
         lds_wait<2>(fa[ks & 1], fb[ks & 1]);  // the two reads of step ks+1 may stay in flight
       } else {
         lds_wait<0>(fa[ks & 1], fb[ks & 1]);
+      }
+      if constexpr (U8) {  // pixel byte -> (pixel - mean), exact in fp32 (v_cvt_f32_ubyte0 + v_sub per operand)
+        // (built in a fresh vector: hipcc 7.2 miscompiles the in-place per-element form `v[i] = f(v[i])` of this update)
+        decltype(fa[0].v) cv;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const float e = fa[ks & 1].v[i];
+          cv[i] = (float)(__builtin_bit_cast(unsigned, e) & 255u) - a.in_mean;
+        }
+        fa[ks & 1].v = cv;
       }
       __builtin_amdgcn_sched_barrier(0);
       mfma_step(fa[ks & 1], fb[ks & 1]);
@@ -1142,7 +1210,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
     }
   }
   if constexpr (EPI != EPI_STD) {
-    brick_epilogue<BM, BN, BK, EPI>(a, acc, smem, tile_m, tile_n, n0, bk_b, bk_t, bk_h, bk_w, wave, lane, tid);
+    brick_epilogue<BM, BN, BK, EPI, U8>(a, acc, smem, tile_m, tile_n, n0, bk_b, bk_t, bk_h, bk_w, wave, lane, tid);
     return;
   }
   // (one epilogue call site: a second inlined copy costs ~25 VGPRs and with them a resident workgroup per CU)
@@ -1529,6 +1597,70 @@ __global__ void build_ktab_kernel(int4* __restrict__ ktab, int kt, int kh, int k
       f = make_int2(0, (int)(1u << 30));
     }
     t2[k] = f;
+  }
+}
+
+// ---- tables of the uint8-frame stem (conv3d_igemm_dma_kernel<..., U8 = true>) ---------------------------------------------
+// {byte offset, tap bits} per k-row for frames stored (F, FH, FW, C): table 0 as stored, table 1 for the mirrored crops
+// (tap dw of a mirrored crop is source column -dw; the kernel moves its window origin (kw-1) columns left to keep offsets >= 0)
+__global__ void build_ktab_u8_kernel(int2* __restrict__ tab, int kt, int kh, int kw, int C, int K, int Kpad, int FWC, int FHWC) {
+  const int taps = kt * kh * kw;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < Kpad; k += gridDim.x * blockDim.x) {
+    int2 f = make_int2(0, (int)(1u << 30)), g = f;  // padding rows: never inside
+    if (k < K) {
+      const int ci = k / taps, tap = k % taps;
+      const int dt = tap / (kh * kw), r = tap % (kh * kw);
+      const int dh = r / kw, dw = r % kw;
+      const int bits = (int)((1u << dt) | (1u << (10 + dh)) | (1u << (20 + dw)));
+      f = make_int2(ci + dt * FHWC + dh * FWC + dw * C, bits);
+      g = make_int2(ci + dt * FHWC + dh * FWC + (kw - 1 - dw) * C, bits);
+    }
+    tab[k] = f;
+    tab[Kpad + k] = g;
+  }
+}
+
+// cls = {nt, nh, nw, 0}, class[To], class[Ho], class[Wo], mask[To], mask[Ho], mask[Wo]: outputs with the same set of taps
+// inside the clip share a class (3 x 4 x 4 classes for the 5x7x7 stride-2 stem at 16 x 224 x 224)
+__global__ void u8_pad_classes_kernel(int* __restrict__ cls, int To, int Ho, int Wo, int kt, int kh, int kw, int st, int sh, int sw,
+                                      int pt, int ph, int pw, int T, int H, int W) {
+  if (threadIdx.x || blockIdx.x) return;
+  int* c[3] = {cls + 4, cls + 4 + To, cls + 4 + To + Ho};
+  int* m[3] = {cls + 4 + To + Ho + Wo, cls + 4 + 2 * To + Ho + Wo, cls + 4 + 2 * To + 2 * Ho + Wo};
+  const int O[3] = {To, Ho, Wo}, k[3] = {kt, kh, kw}, s[3] = {st, sh, sw}, p[3] = {pt, ph, pw}, I[3] = {T, H, W};
+  for (int d = 0; d < 3; ++d) {
+    int n = 0;
+    for (int o = 0; o < O[d]; ++o) {
+      const int mask = (int)tap_bits(o * s[d] - p[d], k[d], I[d]);
+      int j = 0;
+      while (j < n && m[d][j] != mask) ++j;
+      if (j == n) m[d][n++] = mask;
+      c[d][o] = j;
+    }
+    cls[d] = n;
+  }
+  cls[3] = 0;
+}
+
+__global__ void u8_pad_corr_kernel(const float* __restrict__ wp, const int* __restrict__ cls, float* __restrict__ corr, int cap, int To,
+                                   int Ho, int Wo, int Cin, int kt, int kh, int kw, int Cout, float mean) {
+  const int nt = cls[0], nh = cls[1], nw = cls[2];
+  const int* mt = cls + 4 + To + Ho + Wo;
+  const int* mh = mt + To;
+  const int* mw = mh + Ho;
+  const int total = nt * nh * nw * Cout;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total && idx < cap; idx += gridDim.x * blockDim.x) {
+    const int n = idx % Cout, c = idx / Cout;
+    const int wc = c % nw, hc = (c / nw) % nh, tc = c / (nw * nh);
+    const unsigned bt = (unsigned)mt[tc], bh = (unsigned)mh[hc], bw = (unsigned)mw[wc];
+    double sum = 0.0;
+    int k = 0;
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int dt = 0; dt < kt; ++dt)
+        for (int dh = 0; dh < kh; ++dh)
+          for (int dw = 0; dw < kw; ++dw, ++k)
+            if (!((bt >> dt) & (bh >> dh) & (bw >> dw) & 1u)) sum += (double)wp[(size_t)k * Cout + n];
+    corr[idx] = (float)((double)mean * sum);
   }
 }
 
@@ -2049,6 +2181,94 @@ extern "C" int advhip_conv3d_bn_relu_maxpool233_f32(const advhip_conv3d_desc* d,
   ADVHIP_REQUIRE(nbw <= MERGE_MAX_NBW, "conv3d+pool233: pooled width %d above %d", Wp, MERGE_MAX_NBW * 8 - 1);
   const long long rows = (long long)d->B * a.tiles_n * 2 * Tp * Hp;
   ADVHIP_REQUIRE(rows < (1ll << 31), "conv3d+pool233: too many output rows");
+  const unsigned gx = (unsigned)std::min<long long>(rows, 1 << 20), gy = (unsigned)((rows + gx - 1) / gx);
+  hipLaunchKernelGGL(stem_pool_merge_kernel, dim3(gx, gy), dim3(256), (size_t)2 * nbw * 288 * sizeof(float), st, reinterpret_cast<const float*>(workspace), y, d->Cout, Tp,
+                     Hp, Wp, nbh, nbw, a.tiles_n, FastDiv::make((unsigned)Wp), rows, ybs);
+  return check_launch("stem_pool_merge");
+}
+
+// ---- stem + maxpool1 straight from resized uint8 frames (TenCrop, float conversion and normalisation in the load stage) ----
+namespace advhip {
+static int u8_class_cap(int O, int k) { return std::min(O, 2 * k + 1); }
+static int u8_check_frames(const advhip_conv3d_desc* d, int64_t F, int FH, int FW) {
+  ADVHIP_REQUIRE(F > 0 && F % d->T == 0, "conv3d u8: %lld frames are not whole clips of %d", (long long)F, d->T);
+  ADVHIP_REQUIRE(FH >= d->H && FW >= d->W, "conv3d u8: frames (%d x %d) smaller than the %d x %d crop", FH, FW, d->H, d->W);
+  ADVHIP_REQUIRE(d->kt <= 10 && d->kh <= 10 && d->kw <= 10, "conv3d u8: kernel extents above 10");
+  ADVHIP_REQUIRE(F * FH * FW * d->Cin < (1ll << 31) - (1 << 24), "conv3d u8: frames tensor above 2 GiB");
+  return ADVHIP_OK;
+}
+}  // namespace advhip
+
+extern "C" int advhip_conv3d_u8_table_sizes(const advhip_conv3d_desc* d, int64_t* ktab_ints, int64_t* cls_ints, int64_t* corr_floats) {
+  if (int rc = validate(d)) return rc;
+  const Geometry g = geometry(d);
+  if (ktab_ints) *ktab_ints = 4ll * g.Kpad;
+  if (cls_ints) *cls_ints = 4 + 2ll * (g.To + g.Ho + g.Wo);
+  if (corr_floats) *corr_floats = (int64_t)u8_class_cap(g.To, d->kt) * u8_class_cap(g.Ho, d->kh) * u8_class_cap(g.Wo, d->kw) * d->Cout;
+  return ADVHIP_OK;
+}
+
+extern "C" int advhip_conv3d_u8_build_tables(const advhip_conv3d_desc* d, int32_t FH, int32_t FW, const float* w_packed, float mean,
+                                             int32_t* ktab_u8, int32_t* cls, float* corr, void* stream) {
+  if (int rc = validate(d)) return rc;
+  ADVHIP_REQUIRE(w_packed && ktab_u8 && cls && corr, "conv3d u8 tables: null pointer");
+  if (int rc = u8_check_frames(d, d->T, FH, FW)) return rc;
+  const Geometry g = geometry(d);
+  int64_t cap = 0;
+  advhip_conv3d_u8_table_sizes(d, nullptr, nullptr, &cap);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(build_ktab_u8_kernel, dim3((g.Kpad + 255) / 256), dim3(256), 0, st, reinterpret_cast<int2*>(ktab_u8), d->kt, d->kh,
+                     d->kw, d->Cin, g.K, g.Kpad, FW * d->Cin, FH * FW * d->Cin);
+  hipLaunchKernelGGL(u8_pad_classes_kernel, dim3(1), dim3(64), 0, st, cls, g.To, g.Ho, g.Wo, d->kt, d->kh, d->kw, d->st, d->sh, d->sw,
+                     d->pt, d->ph, d->pw, d->T, d->H, d->W);
+  hipLaunchKernelGGL(u8_pad_corr_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, st, w_packed, cls, corr, (int)cap, g.To, g.Ho,
+                     g.Wo, d->Cin, d->kt, d->kh, d->kw, d->Cout, mean);
+  return check_launch("conv3d_u8_build_tables");
+}
+
+extern "C" int advhip_conv3d_u8_tencrop_bn_relu_maxpool233_f32(const advhip_conv3d_desc* d, const uint8_t* frames, int64_t F, int32_t FH,
+                                                               int32_t FW, int64_t first_crop_clip, const float* w_packed,
+                                                               const int32_t* ktab_u8, const int32_t* cls, const float* corr,
+                                                               const float* scale, const float* shift, float mean, float stdv, float* y,
+                                                               int64_t y_batch_stride, void* workspace, int64_t workspace_bytes,
+                                                               void* stream) {
+  if (int rc = validate(d)) return rc;
+  ADVHIP_REQUIRE(frames && w_packed && ktab_u8 && cls && corr && scale && shift && y, "conv3d u8+pool233: null pointer");
+  ADVHIP_REQUIRE(stdv != 0.f, "conv3d u8+pool233: std must be non-zero");
+  if (int rc = u8_check_frames(d, F, FH, FW)) return rc;
+  ADVHIP_REQUIRE(first_crop_clip >= 0 && first_crop_clip + d->B <= F / d->T * 10,
+                 "conv3d u8+pool233: crop-clips [%lld, %lld) outside the %lld clips x 10 crops of the frames", (long long)first_crop_clip,
+                 (long long)first_crop_clip + d->B, (long long)(F / d->T));
+  const Geometry g = geometry(d);
+  const int Tp = pool_out(g.To, 2, 2), Hp = pool_out(g.Ho, 3, 2), Wp = pool_out(g.Wo, 3, 2);
+  ADVHIP_REQUIRE(Tp > 0 && Hp > 0 && Wp > 0, "conv3d u8+pool233: conv output (%d,%d,%d) smaller than the (2,3,3) window", g.To, g.Ho, g.Wo);
+  const int64_t need = advhip_conv3d_relu_maxpool233_workspace_bytes(d);
+  ADVHIP_REQUIRE(workspace != nullptr && workspace_bytes >= need && need < 0xF0000000ll,
+                 "conv3d u8+pool233: needs a %lld-byte workspace (got %lld)", (long long)need, (long long)workspace_bytes);
+  const long long y_dense = (long long)d->Cout * Tp * Hp * Wp;
+  const long long ybs = y_batch_stride > 0 ? y_batch_stride : y_dense;
+  ADVHIP_REQUIRE(ybs >= y_dense, "conv3d u8+pool233: y batch stride %lld smaller than one pooled sample (%lld)", ybs, y_dense);
+  ConvArgs a;
+  if (int rc = fill_pool_args(a, d, g, reinterpret_cast<const float*>(frames), 0, w_packed, nullptr, scale, shift, false)) return rc;
+  a.u8_first = (int)first_crop_clip; a.u8_FH = FH; a.u8_FW = FW;
+  // torchvision center_crop: int(round((H - crop) / 2.0)) with Python's round-half-to-even
+  auto half_even = [](int v) { return (v % 2 == 0) ? v / 2 : ((v / 2) % 2 == 0 ? v / 2 : v / 2 + 1); };
+  a.u8_ctop = half_even(FH - d->H); a.u8_cleft = half_even(FW - d->W);
+  a.in_mean = mean; a.in_std = stdv;
+  a.ktab_u8 = reinterpret_cast<const int2*>(ktab_u8); a.pad_cls = cls; a.pad_corr = corr;
+  // byte offsets: the window origin of a border output lies up to (pt, ph, pw + kw - 1) before the crop's corner
+  a.pad_off = (d->pt * FH * FW + d->ph * FW + d->pw + d->kw) * d->Cin;
+  a.x_bytes = (unsigned)(F * FH * FW * d->Cin + a.pad_off);
+  a.y = reinterpret_cast<float*>(workspace);
+  a.y_bstride = 0; a.Tp = Tp; a.relu = 1;
+  const int nbh = (2 * Hp + 1 + 3) / 4, nbw = (2 * Wp + 1 + 15) / 16;
+  set_bricks(a, Tp, nbh, nbw);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, true, 2, EPI_POOL233, true>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, st, a);
+  if (int rc = check_launch("conv3d u8+pool233")) return rc;
+  ADVHIP_REQUIRE(nbw <= MERGE_MAX_NBW, "conv3d u8+pool233: pooled width %d above %d", Wp, MERGE_MAX_NBW * 8 - 1);
+  const long long rows = (long long)d->B * a.tiles_n * 2 * Tp * Hp;
+  ADVHIP_REQUIRE(rows < (1ll << 31), "conv3d u8+pool233: too many output rows");
   const unsigned gx = (unsigned)std::min<long long>(rows, 1 << 20), gy = (unsigned)((rows + gx - 1) / gx);
   hipLaunchKernelGGL(stem_pool_merge_kernel, dim3(gx, gy), dim3(256), (size_t)2 * nbw * 288 * sizeof(float), st, reinterpret_cast<const float*>(workspace), y, d->Cout, Tp,
                      Hp, Wp, nbh, nbw, a.tiles_n, FastDiv::make((unsigned)Wp), rows, ybs);

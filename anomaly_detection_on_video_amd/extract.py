@@ -42,21 +42,28 @@ _LANES: Dict[torch.device, list] = {}
 
 
 @torch.no_grad()
-def run_chunks_on_lanes(model, chunks, lanes: Optional[int] = None) -> torch.Tensor:
+def run_chunks_on_lanes(model, chunks, lanes: Optional[int] = None, fn=None, prepare=None) -> torch.Tensor:
     """Backbone forwards of independent chunks of crop-clips -> (sum of rows, 2048), in order.  One chunk: a plain
     `model(chunk)` (which splits its batch over two streams itself).  Several: chunk i runs on HIP stream lane
     i % lanes as whole-batch launches, so up to `lanes` forwards are in flight and one chunk's kernel tails and
     memory-bound launches overlap another's MFMA-bound ones (same kernels, bit-identical rows; pipeline.py has the
     measurements).  The caller's stream waits for every lane before the rows are concatenated."""
     lanes = int(os.environ.get("ADV_PIPELINE_LANES", "3")) if lanes is None else lanes
-    if len(chunks) <= 1 or lanes <= 1 or not chunks[0].is_cuda:  # (CPU tensors: host-logic tests with a stand-in model)
+    if fn is not None:  # chunks are descriptors (e.g. crop-clip ranges of a frames tensor), fn(chunk) runs one; prepare() builds lazy state
+        if len(chunks) <= 1 or lanes <= 1:
+            return torch.cat([fn(c).reshape(-1, 2048) for c in chunks], dim=0)
+        dev = next(model.parameters()).device
+    elif len(chunks) <= 1 or lanes <= 1 or not chunks[0].is_cuda:  # (CPU tensors: host-logic tests with a stand-in model)
         return torch.cat([model(c.contiguous()).reshape(-1, 2048) for c in chunks], dim=0)
-    dev = chunks[0].device
+    else:
+        dev = chunks[0].device
     pool = _LANES.setdefault(dev, [])
     while len(pool) < lanes:
         pool.append(torch.cuda.Stream(device=dev))
     cur = torch.cuda.current_stream(dev)
-    if hasattr(model, "ensure_tables"):
+    if prepare is not None:
+        prepare()
+    elif hasattr(model, "ensure_tables"):
         model.ensure_tables(tuple(chunks[0].shape[2:]))  # lazily built state: before the lanes fork
     ready = torch.cuda.Event()
     ready.record(cur)
@@ -67,9 +74,12 @@ def run_chunks_on_lanes(model, chunks, lanes: Optional[int] = None) -> torch.Ten
             lane = pool[i % lanes]
             with torch.cuda.stream(lane):
                 lane.wait_event(ready)
-                c = c.contiguous()
-                c.record_stream(lane)
-                out = model(c).reshape(-1, 2048)
+                if fn is not None:
+                    out = fn(c).reshape(-1, 2048)
+                else:
+                    c = c.contiguous()
+                    c.record_stream(lane)
+                    out = model(c).reshape(-1, 2048)
                 done = torch.cuda.Event()
                 done.record(lane)
             cur.wait_event(done)
@@ -129,9 +139,31 @@ def extract_video_frames(model, frames: torch.Tensor, frames_per_clip: int = FRA
     rows = []
     step = clips_per_step * frames_per_clip
     max_cc = kw.get("max_crop_clips", 32)
+    direct = hasattr(model, "forward_frames") and hasattr(model, "frames_fused") and model.frames_fused()
     for f0 in range(0, frames.shape[0], step):
-        x = mil_ops.tencrop_normalize_u8(frames[f0 : f0 + step].to(dev, non_blocking=True), frames_per_clip, crop)
-        rows.append(run_chunks_on_lanes(model, [x[i : i + max_cc] for i in range(0, x.shape[0], max_cc)]))
+        fr = frames[f0 : f0 + step].to(dev, non_blocking=True)
+        if not direct:
+            x = mil_ops.tencrop_normalize_u8(fr, frames_per_clip, crop)
+            rows.append(run_chunks_on_lanes(model, [x[i : i + max_cc] for i in range(0, x.shape[0], max_cc)]))
+            continue
+        # the stem kernel reads the uint8 pixels itself (TenCrop + float + normalise in its load stage): only LoopPad is left,
+        # and only for a last clip shorter than frames_per_clip (src/gtransforms.py:119-132) -- a uint8 gather of <= 15 frames
+        short = fr.shape[0] % frames_per_clip
+        if short:
+            whole = fr.shape[0] - short
+            idx = torch.arange(frames_per_clip, device=dev) % short + whole
+            fr = torch.cat([fr[:whole], fr[idx]], dim=0)
+        fr = fr.contiguous()
+        n = fr.shape[0] // frames_per_clip * NCROPS
+        ranges = [(i, min(max_cc, n - i)) for i in range(0, n, max_cc)]
+
+        def run_range(r, fr=fr):
+            fr.record_stream(torch.cuda.current_stream(dev))  # (read on a lane stream, allocated on the caller's)
+            return model.forward_frames(fr, r[0], r[1], frames_per_clip, crop)
+
+        rows.append(run_chunks_on_lanes(
+            model, ranges, fn=run_range,
+            prepare=lambda fr=fr: [model.ensure_frame_tables(tuple(fr.shape[1:3]), frames_per_clip, crop, b) for b in sorted({r[1] for r in ranges})]))
     out = torch.cat(rows, dim=0).reshape(-1, NCROPS, 2048).cpu().numpy()
     return np.squeeze(out)
 

@@ -315,6 +315,46 @@ class I3Res50(nn.Module):
                 mark()
         return x
 
+    def frames_fused(self) -> bool:
+        """True when forward_frames feeds the stem kernel with uint8 pixels directly (stem + maxpool1 fused and present)."""
+        self.prepare()
+        u = self._plan[0]
+        return bool(self.fuse_pool and u.kind == "stem" and u.pool_unit is not None and tuple(u.pool_unit.kernel) == (2, 3, 3)
+                    and tuple(u.pool_unit.stride) == (2, 2, 2))
+
+    def ensure_frame_tables(self, frame_hw: Tuple[int, int], frames_per_clip: int = 16, crop: int = 224, batch: Optional[int] = None) -> None:
+        """ensure_tables for forward_frames: every lazily built table, on the current stream, before streams fork."""
+        self.ensure_tables((frames_per_clip, crop, crop), batch)
+        if self.frames_fused():
+            ops.ensure_u8_tables(self._plan[0].convs[0], tuple(frame_hw), (frames_per_clip, crop, crop))
+
+    def forward_frames(self, frames: torch.Tensor, first: int, count: int, frames_per_clip: int = 16, crop: int = 224) -> torch.Tensor:
+        """Features (count, 2048, 1, 1, 1) of crop-clips [first, first + count) of a video given as resized uint8 frames
+        (F, FH, FW, 3), F whole clips; row = clip * 10 + crop in TenCrop order.  What the reference does on the host per clip
+        -- GroupTenCrop, ToTensor, GroupNormalize, the (T,C)->(C,T) permute (src/dataset.py:175-195, src/gtransforms.py:29-38,
+        57-73, extract_features.py:83-89) -- happens in the load stage of the stem kernel: the fp32 ten-crop tensor never exists."""
+        if self.training:
+            raise _lib.HipExtensionError("I3Res50 HIP path implements eval-mode BatchNorm only; call .eval()")
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or not frames.is_cuda:
+            raise _lib.HipExtensionError(f"forward_frames wants uint8 (F,H,W,3) frames on the GPU, got {frames.dtype} {tuple(frames.shape)} on {frames.device}")
+        self.prepare()
+        with torch.no_grad():
+            if not self.frames_fused():  # other stems / ADV_I3D_FUSE_POOL=0: TenCrop + normalise as its own HIP pass
+                from . import mil_ops
+
+                return self.forward_single(mil_ops.tencrop_normalize_u8(frames, frames_per_clip, crop)[first : first + count])
+            stem, pu = self._plan[0], self._plan[0].pool_unit
+            if pu.cat_channels:  # straight into the [x ; h] buffer of layer1.0, like _Unit.run
+                d = ops.conv_pool_out_dims((frames_per_clip, crop, crop), stem.convs[0], pu.kernel, pu.stride)
+                x = torch.empty((count, stem.convs[0].cout + pu.cat_channels) + d, device=frames.device, dtype=torch.float32)
+                ops.conv3d_u8_tencrop_bn_relu_maxpool233(frames, stem.convs[0], first, count, frames_per_clip, crop, out=x[:, : stem.convs[0].cout])
+            else:
+                x = ops.conv3d_u8_tencrop_bn_relu_maxpool233(frames, stem.convs[0], first, count, frames_per_clip, crop)
+            for u in self._plan[1:]:
+                if not u.absorbed:
+                    x = u.run(x, True)
+        return x
+
     def ensure_tables(self, thw: Tuple[int, int, int], batch: Optional[int] = None) -> None:
         """Pack the weights and build every conv's gather table for clips of dims (T,H,W) on the CURRENT stream;
         with `batch`, also the split-bf16 weight images of every conv whose resolved choice for (batch,T,H,W) is a

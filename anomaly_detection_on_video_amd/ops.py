@@ -240,6 +240,67 @@ def conv3d_bn_relu_maxpool233(x: torch.Tensor, pc: PackedConv, out: Optional[tor
     return y
 
 
+PIXEL_MEAN, PIXEL_STD = 114.75, 57.375  # GroupNormalize constants, src/dataset.py:180-181
+
+
+def ensure_u8_tables(pc: "PackedConv", frame_hw: Tuple[int, int], clip_thw: Tuple[int, int, int], mean: float = PIXEL_MEAN):
+    """Gather / border tables of the uint8-frame stem for frames of (FH, FW) and clips of (T, crop, crop); cached on the conv
+    (built on the current stream: callers that fork streams build them first, like the other lazily built tables)."""
+    key = (tuple(frame_hw), tuple(clip_thw), float(mean))
+    cache = pc.__dict__.setdefault("_u8_tables", {})
+    tabs = cache.get(key)
+    if tabs is None:
+        d = pc.desc(1, *clip_thw, True, 0, 1)
+        lib = _lib.load()
+        nk, nc, nf = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib.advhip_conv3d_u8_table_sizes(C.byref(d), C.byref(nk), C.byref(nc), C.byref(nf)), "conv3d_u8_table_sizes")
+        dev = pc.w_packed.device
+        ktab = torch.empty((nk.value,), device=dev, dtype=torch.int32)
+        cls = torch.empty((nc.value,), device=dev, dtype=torch.int32)
+        corr = torch.empty((nf.value,), device=dev, dtype=torch.float32)
+        check(lib.advhip_conv3d_u8_build_tables(C.byref(d), frame_hw[0], frame_hw[1], ptr(pc.w_packed), C.c_float(mean), ptr(ktab),
+                                                ptr(cls), ptr(corr), stream(dev)), f"conv3d_u8_build_tables[{pc.name}]")
+        tabs = cache[key] = (ktab, cls, corr)
+    return tabs
+
+
+def conv3d_u8_tencrop_bn_relu_maxpool233(frames: torch.Tensor, pc: "PackedConv", first: int, count: int, frames_per_clip: int = 16,
+                                         crop: int = 224, out: Optional[torch.Tensor] = None, mean: float = PIXEL_MEAN,
+                                         std: float = PIXEL_STD) -> torch.Tensor:
+    """The stem (conv1 + bn1 + relu + maxpool1, src/i3d.py:303-306) of crop-clips [first, first + count) of a video given as
+    resized uint8 frames (F, FH, FW, 3): row = clip * 10 + crop (TenCrop order).  TenCrop, float conversion and
+    (x - mean) / std happen in the conv's load stage (src/gtransforms.py:29-38,57-73, extract_features.py:83-89)."""
+    require_gpu(frames)
+    require_gpu(out, contiguous=False)
+    if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != pc.cin:
+        raise ValueError(f"{pc.name}: expected uint8 (F,H,W,{pc.cin}) frames, got {frames.dtype} {tuple(frames.shape)}")
+    F, FH, FW, _ = frames.shape
+    if F % frames_per_clip or FH < crop or FW < crop:
+        raise ValueError(f"{pc.name}: {F} frames of {FH}x{FW} are not whole {frames_per_clip}-frame clips of at least {crop}x{crop}")
+    if count <= 0 or first < 0 or first + count > F // frames_per_clip * 10:
+        raise ValueError(f"{pc.name}: crop-clips [{first}, {first + count}) outside the video's {F // frames_per_clip * 10}")
+    d = pc.desc(count, frames_per_clip, crop, crop, True, 0, 1)
+    lib = _lib.load()
+    tp, hp, wp = C.c_int32(), C.c_int32(), C.c_int32()
+    check(lib.advhip_conv3d_pool_out_dims(C.byref(d), 2, 3, 3, 2, 2, 2, C.byref(tp), C.byref(hp), C.byref(wp)), "conv3d_pool_out_dims")
+    shape = (count, pc.cout, tp.value, hp.value, wp.value)
+    if min(shape) <= 0:
+        raise ValueError(f"{pc.name}: clips of ({frames_per_clip},{crop},{crop}) too small for conv + (2,3,3) pooling")
+    y = out if out is not None else torch.empty(shape, device=frames.device, dtype=torch.float32)
+    if tuple(y.shape) != shape or y.dtype != torch.float32 or y.device != frames.device:
+        raise ValueError(f"{pc.name}: out {tuple(y.shape)} != {shape}")
+    ktab, cls, corr = ensure_u8_tables(pc, (FH, FW), (frames_per_clip, crop, crop), mean)
+    need = lib.advhip_conv3d_relu_maxpool233_workspace_bytes(C.byref(d))
+    if need < 0:
+        check(int(need), f"conv3d_relu_maxpool233_workspace_bytes[{pc.name}]")
+    ws = workspace(frames.device, need)
+    check(lib.advhip_conv3d_u8_tencrop_bn_relu_maxpool233_f32(C.byref(d), ptr(frames), F, FH, FW, first, ptr(pc.w_packed), ptr(ktab),
+                                                              ptr(cls), ptr(corr), ptr(pc.scale), ptr(pc.shift), C.c_float(mean),
+                                                              C.c_float(std), ptr(y), batch_stride(y), ptr(ws), need, stream()),
+          f"conv3d_u8+pool233[{pc.name}]")
+    return y
+
+
 def conv3d_bn_act_maxpool211(x: torch.Tensor, pc: PackedConv, relu: bool = True, residual: Optional[torch.Tensor] = None,
                              out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """maxpool3d(act(conv3d(x) * scale + shift (+ residual)), (2,1,1), (2,1,1)) in one launch, for a 1x1x1 stride-1 conv

@@ -1,0 +1,131 @@
+"""The stem fed by resized uint8 frames (TenCrop + float + normalise in the conv's load stage) -- run with -m gpu.
+
+Parity chain: the numpy restatement of TenCropVideoFrameDataset (oracle/host_oracle.ten_crop_clips, torchvision's published
+TenCrop geometry; /root/reference/src/dataset.py:175-195, src/gtransforms.py:29-38,57-73) -> the oracle's conv + BN + ReLU
+-> max_pool3d (/root/reference/src/i3d.py:303-306).  The uint8 kernel computes sum w * (pixel - mean) exactly in fp32 and
+applies 1/std with the BN scale, the reference rounds (pixel - mean) / std first: 2e-5 of the output scale, element-wise
+|a - b| <= 1e-3 |b| + 1e-3 rms(b)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close_elementwise, rel_err
+from anomaly_detection_on_video_amd.weights import synth_tensor
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _stem(name="u8stem"):
+    from anomaly_detection_on_video_amd import ops
+
+    dev = _dev()
+    k, s, p = (5, 7, 7), (2, 2, 2), (2, 3, 3)
+    wt = synth_tensor(f"{name}.w", (64, 3) + k, scale=float(np.sqrt(6.0 / (3 * 5 * 7 * 7))))
+    g = synth_tensor(f"{name}.g", (64,), scale=0.5, offset=1.0)
+    be = synth_tensor(f"{name}.b", (64,), scale=0.25)
+    mu = synth_tensor(f"{name}.m", (64,), scale=0.25)
+    var = synth_tensor(f"{name}.v", (64,), scale=0.5, offset=1.0)
+    pc = ops.pack_conv(wt.to(dev), g.to(dev), be.to(dev), mu.to(dev), var.to(dev), 1e-5, s, p, name=name)
+    return pc, (wt, g, be, mu, var)
+
+
+def _frames(seed, shape):
+    rng = np.random.default_rng(seed)
+    f = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    f[0, :3, :5] = 0      # extreme pixel values in a corner every corner crop / its mirror sees
+    f[-1, -3:, -5:] = 255
+    return f
+
+
+# (frames F, FH, FW), frames per clip, crop, (first, count) ranges of crop-clips
+CASES = [
+    ((32, 256, 340), 16, 224, [(0, 20), (7, 11)]),          # the reference's geometry; a range that starts mid-clip
+    ((16, 40, 52), 8, 32, [(0, 20), (3, 1), (15, 5)]),      # small: checked against the CPU oracle too
+    ((12, 37, 45), 4, 30, [(0, 30), (9, 13)]),              # odd margins (centre crop rounds half to even), crop not a multiple of the brick
+    ((6, 24, 24), 6, 24, [(0, 10)]),                        # crop == frame: all five crops coincide
+    ((10, 33, 61), 5, 23, [(4, 16)]),                       # odd crop and clip length
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(c[0]) + f"/{c[1]}/{c[2]}" for c in CASES])
+def test_u8_stem_matches_float_pipeline_and_oracle(case):
+    from anomaly_detection_on_video_amd import mil_ops, ops
+    from oracle import host_oracle, i3d_oracle
+
+    (F, FH, FW), fpc, crop, ranges = case
+    pc, (wt, g, be, mu, var) = _stem()
+    frames = _frames(F * 1000 + FH, (F, FH, FW, 3))
+    fd = torch.from_numpy(frames).to(_dev())
+    crops = mil_ops.tencrop_normalize_u8(fd, fpc, crop)            # (n_clips * 10, 3, fpc, crop, crop) fp32 on the device
+    ref_all = ops.conv3d_bn_relu_maxpool233(crops, pc)             # the fp32-input product path (bit-exact vs conv + pool)
+    scale = float(ref_all.abs().max())
+    for first, count in ranges:
+        got = ops.conv3d_u8_tencrop_bn_relu_maxpool233(fd, pc, first, count, fpc, crop)
+        ref = ref_all[first : first + count]
+        assert got.shape == ref.shape
+        err = float((got - ref).abs().max()) / scale
+        assert err < 2e-5, f"crop-clips [{first},{first + count}): {err:.3e}"
+        assert_close_elementwise(got.cpu(), ref.cpu())
+    if F * FH * FW <= 16 * 40 * 52:  # the CPU oracle end to end: numpy TenCrop -> torch conv / BN / ReLU / max_pool3d
+        x = torch.from_numpy(host_oracle.ten_crop_clips(frames, fpc, crop)).reshape(-1, 3, fpc, crop, crop)
+        assert torch.equal(crops.cpu(), x)
+        want = torch.nn.functional.max_pool3d(i3d_oracle.conv_bn_act(x, wt, g, be, mu, var, (2, 2, 2), (2, 3, 3), None, True), (2, 3, 3), (2, 2, 2))
+        got = ops.conv3d_u8_tencrop_bn_relu_maxpool233(fd, pc, 0, x.shape[0], fpc, crop)
+        assert rel_err(got.cpu(), want) < 2e-5
+        assert_close_elementwise(got.cpu(), want)
+
+
+def test_u8_stem_constant_frames_hit_only_the_border_table():
+    """All pixels = 115 -> (pixel - mean) = 0.25 everywhere: interior outputs are 0.25 * sum(w) and the border outputs differ
+    from them only through the taps outside the clip -- a direct check of the per-class correction (a missing correction
+    would be off by 114.75 * the outside weights, ~100x the signal)."""
+    from anomaly_detection_on_video_amd import mil_ops, ops
+
+    pc, _ = _stem("u8const")
+    fd = torch.full((16, 64, 80, 3), 115, dtype=torch.uint8, device=_dev())
+    got = ops.conv3d_u8_tencrop_bn_relu_maxpool233(fd, pc, 0, 10, 16, 56)
+    ref = ops.conv3d_bn_relu_maxpool233(mil_ops.tencrop_normalize_u8(fd, 16, 56), pc)
+    assert float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_u8_stem_writes_into_a_channel_slice_and_rejects_bad_ranges():
+    from anomaly_detection_on_video_amd import ops
+
+    pc, _ = _stem()
+    fd = torch.from_numpy(_frames(5, (16, 40, 52, 3))).to(_dev())
+    dense = ops.conv3d_u8_tencrop_bn_relu_maxpool233(fd, pc, 2, 6, 8, 32)
+    wide = torch.full((6, 128) + tuple(dense.shape[2:]), -3.0, device=_dev())
+    ops.conv3d_u8_tencrop_bn_relu_maxpool233(fd, pc, 2, 6, 8, 32, out=wide[:, :64])
+    assert torch.equal(wide[:, :64], dense) and (wide[:, 64:] == -3.0).all()
+    with pytest.raises(ValueError):
+        ops.conv3d_u8_tencrop_bn_relu_maxpool233(fd, pc, 15, 6, 8, 32)      # past the video's 20 crop-clips
+    with pytest.raises(ValueError):
+        ops.conv3d_u8_tencrop_bn_relu_maxpool233(fd[:15], pc, 0, 5, 8, 32)  # not whole clips
+    with pytest.raises(ValueError):
+        ops.conv3d_u8_tencrop_bn_relu_maxpool233(fd, pc, 0, 5, 8, 64)       # crop larger than the frame
+
+
+def test_forward_frames_whole_backbone_and_fallback(monkeypatch):
+    """I3Res50.forward_frames (uint8 frames -> features) vs forward_single on the fp32 ten-crop tensor: 40 crop-clips of the
+    reference's geometry in the chunks the extraction driver uses, and the separate-pass fallback when the pools are not fused."""
+    from anomaly_detection_on_video_amd import mil_ops
+    from anomaly_detection_on_video_amd.i3d import I3Res50
+    from anomaly_detection_on_video_amd.weights import synth_i3d_state_dict
+
+    m = I3Res50()
+    m.load_state_dict(synth_i3d_state_dict())
+    m = m.eval().to(_dev())
+    fd = torch.from_numpy(_frames(11, (64, 256, 340, 3))).to(_dev())
+    assert m.frames_fused()
+    ref = m(mil_ops.tencrop_normalize_u8(fd, 16, 224))
+    got = torch.cat([m.forward_frames(fd, 0, 32), m.forward_frames(fd, 32, 8)])
+    assert got.shape == ref.shape == (40, 2048, 1, 1, 1)
+    assert rel_err(got.cpu(), ref.cpu()) < 1e-5
+    assert_close_elementwise(got.cpu(), ref.cpu())
+    m.fuse_pool = False
+    assert not m.frames_fused()
+    assert torch.equal(m.forward_frames(fd, 5, 4), m(mil_ops.tencrop_normalize_u8(fd, 16, 224)[5:9]))
