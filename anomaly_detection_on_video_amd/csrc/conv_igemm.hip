@@ -106,10 +106,10 @@ struct ConvArgs {
   // T / H / W above are the clip-local extents (frames per clip, crop size) the tap masks are taken against
   int u8_first, u8_FH, u8_FW;
   int u8_ctop, u8_cleft;    // top / left of the centre crop (round-half-to-even, as torchvision)
-  float in_mean, in_std;    // the operand is (pixel - in_mean); 1 / in_std goes into the BN scale
+  float in_std;             // conv of (pixel - mean) / in_std: the mean through pad_corr, 1 / in_std through the BN scale
   const int2* ktab_u8;      // [2][Kpad] {byte offset, tap bits}: as stored, and mirrored along w
   const int* pad_cls;       // {nt, nh, nw, 0}, class of every output t / h / w (which taps fall outside the clip), class masks
-  const float* pad_corr;    // [nt][nh][nw][Cout]: in_mean * (sum of the weights of the taps outside) -- a zero byte is -in_mean, not 0
+  const float* pad_corr;    // [nt][nh][nw][Cout]: -in_mean * (sum of the weights of the taps inside the clip)
 };
 
 template <int VW>
@@ -714,8 +714,8 @@ __device__ __forceinline__ void brick_epilogue(const ConvArgs& a, f32x4 (&acc)[B
       const float sf = a.shift[n_w];
       float v[16];
       if constexpr (U8) {
-        // the operand was (pixel - mean): 1 / std belongs to the scale, and a tap outside the clip read as byte 0 = -mean
-        // instead of 0 -- add mean * (sum of this channel's weights over those taps), tabulated per border class
+        // the operand was the pixel byte: sum w (pixel - mean) = acc - mean * (sum of this channel's weights over the taps
+        // inside the clip), tabulated per border class (outputs with the same set of taps inside); 1 / std belongs to the scale
         sc = sc / a.in_std;
         const int* cls = a.pad_cls;
         const int nh = cls[1], nw = cls[2];
@@ -1125,18 +1125,28 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
       } else {
         lds_wait<0>(fa[ks & 1], fb[ks & 1]);
       }
-      if constexpr (U8) {  // pixel byte -> (pixel - mean), exact in fp32 (v_cvt_f32_ubyte0 + v_sub per operand)
-        // (built in a fresh vector: hipcc 7.2 miscompiles the in-place per-element form `v[i] = f(v[i])` of this update)
-        decltype(fa[0].v) cv;
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (U8) {
+        // the A operands are pixel bytes (zero-extended by the LDS-DMA): one v_cvt_f32_ubyte0 each, issued in the shadow of
+        // the previous operand's MFMAs.  The operand is the pixel itself; -mean * (sum of the weights of the taps inside the
+        // clip) comes from the border-class table in the epilogue (taps outside read 0 and contribute nothing, as padding should)
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
           const float e = fa[ks & 1].v[i];
-          cv[i] = (float)(__builtin_bit_cast(unsigned, e) & 255u) - a.in_mean;
+          const float ai = (float)(__builtin_bit_cast(unsigned, e) & 255u);
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, fb[ks & 1].v[j], acc[i][j], 0, 0, 0);
         }
-        fa[ks & 1].v = cv;
+        __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);  // cvt 0
+#pragma unroll
+        for (int i = 1; i < FM; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);  // one MFMA, then the next operand's cvt beside it
+          __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x8, FM * FN - (FM - 1), 0);
+      } else {
+        mfma_step(fa[ks & 1], fb[ks & 1]);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_step(fa[ks & 1], fb[ks & 1]);
       __builtin_amdgcn_sched_barrier(0);
     };
     [&]<int... I>(std::integer_sequence<int, I...>) { (body(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, KS>{});
@@ -1659,8 +1669,8 @@ __global__ void u8_pad_corr_kernel(const float* __restrict__ wp, const int* __re
       for (int dt = 0; dt < kt; ++dt)
         for (int dh = 0; dh < kh; ++dh)
           for (int dw = 0; dw < kw; ++dw, ++k)
-            if (!((bt >> dt) & (bh >> dh) & (bw >> dw) & 1u)) sum += (double)wp[(size_t)k * Cout + n];
-    corr[idx] = (float)((double)mean * sum);
+            if ((bt >> dt) & (bh >> dh) & (bw >> dw) & 1u) sum += (double)wp[(size_t)k * Cout + n];
+    corr[idx] = (float)(-(double)mean * sum);
   }
 }
 
@@ -2229,7 +2239,7 @@ extern "C" int advhip_conv3d_u8_build_tables(const advhip_conv3d_desc* d, int32_
 extern "C" int advhip_conv3d_u8_tencrop_bn_relu_maxpool233_f32(const advhip_conv3d_desc* d, const uint8_t* frames, int64_t F, int32_t FH,
                                                                int32_t FW, int64_t first_crop_clip, const float* w_packed,
                                                                const int32_t* ktab_u8, const int32_t* cls, const float* corr,
-                                                               const float* scale, const float* shift, float mean, float stdv, float* y,
+                                                               const float* scale, const float* shift, float stdv, float* y,
                                                                int64_t y_batch_stride, void* workspace, int64_t workspace_bytes,
                                                                void* stream) {
   if (int rc = validate(d)) return rc;
@@ -2254,7 +2264,7 @@ extern "C" int advhip_conv3d_u8_tencrop_bn_relu_maxpool233_f32(const advhip_conv
   // torchvision center_crop: int(round((H - crop) / 2.0)) with Python's round-half-to-even
   auto half_even = [](int v) { return (v % 2 == 0) ? v / 2 : ((v / 2) % 2 == 0 ? v / 2 : v / 2 + 1); };
   a.u8_ctop = half_even(FH - d->H); a.u8_cleft = half_even(FW - d->W);
-  a.in_mean = mean; a.in_std = stdv;
+  a.in_std = stdv;  // (the mean went into `corr` when the tables were built)
   a.ktab_u8 = reinterpret_cast<const int2*>(ktab_u8); a.pad_cls = cls; a.pad_corr = corr;
   // byte offsets: the window origin of a border output lies up to (pt, ph, pw + kw - 1) before the crop's corner
   a.pad_off = (d->pt * FH * FW + d->ph * FW + d->pw + d->kw) * d->Cin;

@@ -295,7 +295,7 @@ def conv3d_u8_tencrop_bn_relu_maxpool233(frames: torch.Tensor, pc: "PackedConv",
         check(int(need), f"conv3d_relu_maxpool233_workspace_bytes[{pc.name}]")
     ws = workspace(frames.device, need)
     check(lib.advhip_conv3d_u8_tencrop_bn_relu_maxpool233_f32(C.byref(d), ptr(frames), F, FH, FW, first, ptr(pc.w_packed), ptr(ktab),
-                                                              ptr(cls), ptr(corr), ptr(pc.scale), ptr(pc.shift), C.c_float(mean),
+                                                              ptr(cls), ptr(corr), ptr(pc.scale), ptr(pc.shift),
                                                               C.c_float(std), ptr(y), batch_stride(y), ptr(ws), need, stream()),
           f"conv3d_u8+pool233[{pc.name}]")
     return y

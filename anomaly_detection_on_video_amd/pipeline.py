@@ -19,6 +19,18 @@ from . import dist as adist
 from . import mil_ops
 
 
+class FrameCrops:
+    """A step's input given as resized uint8 frames instead of fp32 crop-clips: crop-clips [first, first + count) of the
+    video `frames` (F, FH, FW, 3) on the device, row = clip * 10 + crop (TenCrop order).  The backbone's stem reads the pixels
+    itself (I3Res50.forward_frames); a `prepare` callable of step_async may return one of these."""
+
+    def __init__(self, frames: torch.Tensor, first: int, count: int, frames_per_clip: int = 16, crop: int = 224):
+        self.frames, self.first, self.count, self.frames_per_clip, self.crop = frames, first, count, frames_per_clip, crop
+
+    def key(self):
+        return ("u8", self.count, tuple(self.frames.shape[1:3]), self.frames_per_clip, self.crop)
+
+
 class ExtractScoreStream:
     def __init__(self, backbone, scorer, clips_per_video: int = 32, ncrops: int = 10, local_batch: int = 32,
                  world: int = 1, rank: int = 0, feat_dim: int = 2048):
@@ -69,7 +81,10 @@ class ExtractScoreStream:
         compute (`lambda host_u8: mil_ops.normalize_permute_u8(host_u8.to(dev, non_blocking=True))`)."""
         dev = self.ring.device
         if self.lanes <= 1:
-            g, s = self.step(local_clips if prepare is None else prepare(local_clips))
+            x = local_clips if prepare is None else prepare(local_clips)
+            if isinstance(x, FrameCrops):
+                raise ValueError("FrameCrops input needs the lane form of step_async (lanes > 1)")
+            g, s = self.step(x)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
             return StepHandle(ev, g, s)
@@ -94,9 +109,14 @@ class ExtractScoreStream:
                 lane.wait_event(self._tables_built)
             if prepare is not None:
                 local_clips = prepare(local_clips)
-                if tables is not None and table_key(local_clips) not in self._table_dims:
-                    tables(tuple(local_clips.shape[2:]), local_clips.shape[0])
-                    self._table_dims.add(table_key(local_clips))
+                fc = local_clips if isinstance(local_clips, FrameCrops) else None
+                key = fc.key() if fc is not None else table_key(local_clips)
+                if tables is not None and key not in self._table_dims:
+                    if fc is not None:
+                        self.backbone.ensure_frame_tables(tuple(fc.frames.shape[1:3]), fc.frames_per_clip, fc.crop, fc.count)
+                    else:
+                        tables(tuple(local_clips.shape[2:]), local_clips.shape[0])
+                    self._table_dims.add(key)
                     self._tables_built = torch.cuda.Event()
                     self._tables_built.record(lane)
             else:
@@ -104,7 +124,11 @@ class ExtractScoreStream:
             inner = getattr(self.backbone, "streams", 1)
             try:
                 self.backbone.streams = 1  # whole-batch launches per lane; the overlap comes from the other lanes
-                feats = self.backbone(local_clips).reshape(local_clips.shape[0], -1)
+                if isinstance(local_clips, FrameCrops):
+                    fc = local_clips
+                    feats = self.backbone.forward_frames(fc.frames, fc.first, fc.count, fc.frames_per_clip, fc.crop).reshape(fc.count, -1)
+                else:
+                    feats = self.backbone(local_clips).reshape(local_clips.shape[0], -1)
             finally:
                 self.backbone.streams = inner
             if self._ordered is not None:

@@ -177,12 +177,13 @@ int advhip_conv3d_bn_relu_maxpool233_f32(const advhip_conv3d_desc* d, const floa
  * frames: uint8 (F, FH, FW, Cin) -- what the decoder + GroupResize hand over -- F a whole number of clips of d->T frames.
  * Sample b of the launch (d->B of them) is crop-clip first_crop_clip + b = clip * 10 + crop in torchvision's TenCrop order
  * (top-left, top-right, bottom-left, bottom-right, centre, then the same five mirrored along w); d->H / d->W are the crop size.
- * The gather reads the crop's pixels as bytes (`buffer_load_ubyte ... lds`), the operand of the matrix pipe is the exact fp32
- * (pixel - mean), 1/std is folded into the BN scale, and taps outside the clip (which read as byte 0) are put right by a
- * per-border-class table: neither the fp32 ten-crop tensor (385 MB per 40 crop-clips) nor the un-pooled stem output exists.
+ * The gather reads the crop's pixels as bytes (`buffer_load_ubyte ... lds`), the operand of the matrix pipe is the pixel value
+ * (exact in fp32), sum w (pixel - mean) = acc - mean * (sum of the weights of the taps inside the clip) with that sum tabulated
+ * per border class, and 1/std is folded into the BN scale: neither the fp32 ten-crop tensor (385 MB per 40 crop-clips) nor
+ * the un-pooled stem output exists.
  *   advhip_conv3d_u8_table_sizes: element counts of the three tables below (int32 / int32 / float)
  *   advhip_conv3d_u8_build_tables: ktab_u8 = gather offsets (as stored + mirrored), cls = border classes of every output
- *     t / h / w, corr = mean * (sum of the weights of the taps outside) per class and channel; once per (weights, FH, FW, clip dims)
+ *     t / h / w, corr = -mean * (sum of the weights of the taps inside the clip) per class and channel; once per (weights, FH, FW, clip dims)
  * Result: within fp32 rounding of advhip_tencrop_normalize_u8 + advhip_conv3d_bn_relu_maxpool233_f32 (tests: 2e-5). */
 int advhip_conv3d_u8_table_sizes(const advhip_conv3d_desc* d, int64_t* ktab_ints, int64_t* cls_ints, int64_t* corr_floats);
 int advhip_conv3d_u8_build_tables(const advhip_conv3d_desc* d, int32_t FH, int32_t FW, const float* w_packed, float mean,
@@ -190,7 +191,7 @@ int advhip_conv3d_u8_build_tables(const advhip_conv3d_desc* d, int32_t FH, int32
 int advhip_conv3d_u8_tencrop_bn_relu_maxpool233_f32(const advhip_conv3d_desc* d, const uint8_t* frames, int64_t F, int32_t FH,
                                                     int32_t FW, int64_t first_crop_clip, const float* w_packed,
                                                     const int32_t* ktab_u8, const int32_t* cls, const float* corr,
-                                                    const float* scale, const float* shift, float mean, float stdv, float* y,
+                                                    const float* scale, const float* shift, float stdv, float* y,
                                                     int64_t y_batch_stride, void* workspace, int64_t workspace_bytes,
                                                     void* stream);
 

@@ -2,7 +2,7 @@
 
 Parity chain: the numpy restatement of TenCropVideoFrameDataset (oracle/host_oracle.ten_crop_clips, torchvision's published
 TenCrop geometry; /root/reference/src/dataset.py:175-195, src/gtransforms.py:29-38,57-73) -> the oracle's conv + BN + ReLU
--> max_pool3d (/root/reference/src/i3d.py:303-306).  The uint8 kernel computes sum w * (pixel - mean) exactly in fp32 and
+-> max_pool3d (/root/reference/src/i3d.py:303-306).  The uint8 kernel accumulates sum w * pixel, subtracts mean * sum w (tabulated per border class) and
 applies 1/std with the BN scale, the reference rounds (pixel - mean) / std first: 2e-5 of the output scale, element-wise
 |a - b| <= 1e-3 |b| + 1e-3 rms(b)."""
 import numpy as np
