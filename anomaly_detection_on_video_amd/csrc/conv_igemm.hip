@@ -59,6 +59,15 @@ __device__ __forceinline__ unsigned tap_bits(int c0, int k, int n) {
   return bit_range(lo < 31 ? lo : 31, hi < 0 ? 0 : hi);
 }
 
+// border class of a window starting at coordinate c0 (= o*s - p >= -p) of a dimension of extent n: lo taps lie before the clip,
+// hi past its end (both <= p for every output of a floor-mode conv), class = lo * (p + 1) + hi; taps [lo, k - hi) are inside
+__host__ __device__ __forceinline__ int u8_border_class(int c0, int k, int n, int p) {
+  const int lo = c0 < 0 ? -c0 : 0;
+  int hi = c0 + k - n;
+  hi = hi < 0 ? 0 : (hi > p ? p : hi);
+  return (lo > p ? p : lo) * (p + 1) + hi;
+}
+
 struct ConvArgs {
   const float* x;
   const float* w;     // [Kpad][Cout]
@@ -108,8 +117,8 @@ struct ConvArgs {
   int u8_ctop, u8_cleft;    // top / left of the centre crop (round-half-to-even, as torchvision)
   float in_std;             // conv of (pixel - mean) / in_std: the mean through pad_corr, 1 / in_std through the BN scale
   const int2* ktab_u8;      // [2][Kpad] {byte offset, tap bits}: as stored, and mirrored along w
-  const int* pad_cls;       // {nt, nh, nw, 0}, class of every output t / h / w (which taps fall outside the clip), class masks
-  const float* pad_corr;    // [nt][nh][nw][Cout]: -in_mean * (sum of the weights of the taps inside the clip)
+  const float* pad_corr;    // [(pt+1)^2][(ph+1)^2][(pw+1)^2][Cout]: -mean * (sum of the weights of the taps inside the clip), indexed per
+                            //   dimension by border class = (taps before the clip) * (p + 1) + (taps past its end), see u8_border_class
 };
 
 template <int VW>
@@ -621,10 +630,18 @@ constexpr int brick_t(int epi) { return epi == EPI_TSPAN4 ? 4 : 2; }
 // >= 0 after ReLU, so 0 is neutral for the maxima), then the 256 threads pool from LDS with coalesced global accesses.
 constexpr int POOL_SLOTS = 27;  // per brick and channel: 3 row slots x 9 column slots (see brick_epilogue, EPI_POOL233)
 
+// uint8 stem: the border-class correction of a lane's brick row, fetched before the main loop (so that no table read sits
+// in the epilogue of a tile): c[jn] when the 16 outputs of the row share one w class, else read per output from `row`
+struct U8Corr {
+  float c[2];
+  const float* row;  // a.pad_corr + (class_t, class_h, 0, n_w(jn = 0))
+  int uniform;
+};
+
 template <int BM, int BN, int BK, int EPI, bool U8 = false>
 __device__ __forceinline__ void brick_epilogue(const ConvArgs& a, f32x4 (&acc)[BM / 32][BN / 32], float* smem, int tile_m,
                                                int tile_n, int n0, int bk_b, int bk_t, int bk_h, int bk_w, int wave, int lane,
-                                               int tid) {
+                                               int tid, const U8Corr& u8c = U8Corr{}) {
   constexpr int FM = BM / 32, FN = BN / 32, RS = BM + 4, CH = BN / FN;  // CH channels per pass
   static_assert(FM == 4 && FN == 2, "128 x 64 tile");
   constexpr int BT = brick_t(EPI), BH = EPI == EPI_POOL233 ? 4 : 1, BW = BM / (BT * BH);
@@ -717,17 +734,10 @@ __device__ __forceinline__ void brick_epilogue(const ConvArgs& a, f32x4 (&acc)[B
         // the operand was the pixel byte: sum w (pixel - mean) = acc - mean * (sum of this channel's weights over the taps
         // inside the clip), tabulated per border class (outputs with the same set of taps inside); 1 / std belongs to the scale
         sc = sc / a.in_std;
-        const int* cls = a.pad_cls;
-        const int nh = cls[1], nw = cls[2];
-        const int* tcls = cls + 4;
-        const int* hcls = tcls + a.To;
-        const int* wcls = hcls + a.Ho;
-        const int tc = tcls[ot < a.To ? ot : a.To - 1], hc = hcls[oh < a.Ho ? oh : a.Ho - 1];
-        const float* cr = a.pad_corr + (size_t)((tc * nh + hc) * nw) * a.Cout + n_w;
-        const int ow0 = bk_w * BW, owl = a.Wo - 1;
-        const int wc0 = wcls[ow0 < owl ? ow0 : owl], wc1 = wcls[ow0 + 15 < owl ? ow0 + 15 : owl];
-        if (wc0 == wc1) {  // (classes are runs along w: equal at both ends = one class for the whole brick row)
-          const float c0 = cr[(size_t)wc0 * a.Cout];
+        const float* cr = u8c.row + jn;
+        const int ow0 = bk_w * BW;
+        if (u8c.uniform) {
+          const float c0 = u8c.c[jn];
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -737,8 +747,8 @@ __device__ __forceinline__ void brick_epilogue(const ConvArgs& a, f32x4 (&acc)[B
           for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const int ow = ow0 + 4 * r + i;
-              v[4 * r + i] = fmaxf((acc[i][jn][r] + cr[(size_t)wcls[ow < owl ? ow : owl] * a.Cout]) * sc + sf, 0.f);
+              const int wc = u8_border_class((ow0 + 4 * r + i) * a.sw - a.pw, a.kw_, a.W, a.pw);  // (outputs past Wo: any class, zeroed below)
+              v[4 * r + i] = fmaxf((acc[i][jn][r] + cr[(size_t)wc * a.Cout]) * sc + sf, 0.f);
             }
         }
       } else {
@@ -1003,6 +1013,19 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
       vmask = tap_bits(it0, a.kt_, a.T) | (tap_bits(ih0, a.kh_, a.H) << 10) | (tap_bits(iw0, a.kw_, a.W) << 20);
     }
   }
+  U8Corr u8c{};
+  if constexpr (U8) {
+    // this lane's epilogue row: t plane (wave >> 1), brick row (lane >> 4), channels n0 + 2 * ((wave & 1) * 16 + (lane & 15)) + jn
+    const int ot = bk_t * 2 + (wave >> 1), oh = bk_h * BRICK_H + (lane >> 4);
+    const int tc = u8_border_class(ot * a.st - a.pt, a.kt_, a.T, a.pt), hc = u8_border_class(oh * a.sh - a.ph, a.kh_, a.H, a.ph);
+    const int ow0 = bk_w * BRICK_W, owl = ow0 + BRICK_W - 1 < a.Wo ? ow0 + BRICK_W - 1 : a.Wo - 1;
+    const int wc0 = u8_border_class(ow0 * a.sw - a.pw, a.kw_, a.W, a.pw), wc1 = u8_border_class(owl * a.sw - a.pw, a.kw_, a.W, a.pw);
+    const int nch = (a.ph + 1) * (a.ph + 1), ncw = (a.pw + 1) * (a.pw + 1);
+    u8c.row = a.pad_corr + (size_t)((tc * nch + hc) * ncw) * a.Cout + (n0 + 2 * ((wave & 1) * 16 + (lane & 15)));
+    u8c.uniform = wc0 == wc1;  // (classes are runs along w: equal at both ends = one class for the whole brick row)
+    u8c.c[0] = u8c.row[(size_t)wc0 * a.Cout];
+    u8c.c[1] = u8c.row[(size_t)wc0 * a.Cout + 1];
+  }
   const auto rx = U8 ? __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(const_cast<float*>(a.x)) - a.pad_off, 0, a.x_bytes, 0x00020000)
                      : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) - a.pad_off, 0, a.x_bytes, 0x00020000);
   const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
@@ -1116,8 +1139,58 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     lds_read<FM, 0>(fa[0], aa);
     lds_read<FN, 0>(fb[0], ba);
+    // uint8 input: the A operands are pixel bytes (zero-extended by the LDS-DMA), one v_cvt_f32_ubyte0 each.  The operand is
+    // the pixel itself; -mean * (sum of the weights of the taps inside the clip) comes from the border-class table in the
+    // epilogue (taps outside read 0 and contribute nothing, as padding should).  Most of the time one wave per SIMD is in
+    // its MFMA phase (the others wait for their tiles), so a cvt -> MFMA dependency is exposed: the operands of step ks+1
+    // are converted beside the second half of step ks's MFMAs, and only step 0's conversion stands in front of its MFMAs.
+    auto cvt_u8 = [&](Frag<FM>& f) {
+      decltype(f.v) cv;  // (built in a fresh vector: hipcc 7.2 miscompiles the in-place per-element form `v[i] = f(v[i])`)
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const float e = f.v[i];
+        cv[i] = (float)(__builtin_bit_cast(unsigned, e) & 255u);
+      }
+      f.v = cv;
+    };
     auto body = [&](auto ks_c) {
       constexpr int ks = decltype(ks_c)::value;
+      if constexpr (U8) {
+        static_assert(!U8 || FM % 2 == 0, "uint8 input: two halves of the fragment rows");
+        if constexpr (ks == 0) {
+          lds_wait<0>(fa[0], fb[0]);
+          cvt_u8(fa[0]);
+        }
+        if constexpr (ks + 1 < KS) {
+          lds_read<FM, (ks + 1) * 4 * BM * 4>(fa[(ks + 1) & 1], aa);
+          lds_read<FN, (ks + 1) * 4 * BN * 4>(fb[(ks + 1) & 1], ba);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FM / 2; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks & 1].v[i], fb[ks & 1].v[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ks + 1 < KS) {
+          lds_wait<0>(fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+          cvt_u8(fa[(ks + 1) & 1]);
+        }
+#pragma unroll
+        for (int i = FM / 2; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks & 1].v[i], fb[ks & 1].v[j], acc[i][j], 0, 0, 0);
+        if constexpr (ks + 1 < KS) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i) {  // one MFMA, one cvt of the next step beside it
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+      }
       if constexpr (ks + 1 < KS) {
         lds_read<FM, (ks + 1) * 4 * BM * 4>(fa[(ks + 1) & 1], aa);
         lds_read<FN, (ks + 1) * 4 * BN * 4>(fb[(ks + 1) & 1], ba);
@@ -1126,27 +1199,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
         lds_wait<0>(fa[ks & 1], fb[ks & 1]);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (U8) {
-        // the A operands are pixel bytes (zero-extended by the LDS-DMA): one v_cvt_f32_ubyte0 each, issued in the shadow of
-        // the previous operand's MFMAs.  The operand is the pixel itself; -mean * (sum of the weights of the taps inside the
-        // clip) comes from the border-class table in the epilogue (taps outside read 0 and contribute nothing, as padding should)
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-          const float e = fa[ks & 1].v[i];
-          const float ai = (float)(__builtin_bit_cast(unsigned, e) & 255u);
-#pragma unroll
-          for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, fb[ks & 1].v[j], acc[i][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);  // cvt 0
-#pragma unroll
-        for (int i = 1; i < FM; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);  // one MFMA, then the next operand's cvt beside it
-          __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x8, FM * FN - (FM - 1), 0);
-      } else {
-        mfma_step(fa[ks & 1], fb[ks & 1]);
-      }
+      mfma_step(fa[ks & 1], fb[ks & 1]);
       __builtin_amdgcn_sched_barrier(0);
     };
     [&]<int... I>(std::integer_sequence<int, I...>) { (body(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, KS>{});
@@ -1220,7 +1273,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
     }
   }
   if constexpr (EPI != EPI_STD) {
-    brick_epilogue<BM, BN, BK, EPI, U8>(a, acc, smem, tile_m, tile_n, n0, bk_b, bk_t, bk_h, bk_w, wave, lane, tid);
+    brick_epilogue<BM, BN, BK, EPI, U8>(a, acc, smem, tile_m, tile_n, n0, bk_b, bk_t, bk_h, bk_w, wave, lane, tid, u8c);
     return;
   }
   // (one epilogue call site: a second inlined copy costs ~25 VGPRs and with them a resident workgroup per CU)
@@ -1630,46 +1683,19 @@ __global__ void build_ktab_u8_kernel(int2* __restrict__ tab, int kt, int kh, int
   }
 }
 
-// cls = {nt, nh, nw, 0}, class[To], class[Ho], class[Wo], mask[To], mask[Ho], mask[Wo]: outputs with the same set of taps
-// inside the clip share a class (3 x 4 x 4 classes for the 5x7x7 stride-2 stem at 16 x 224 x 224)
-__global__ void u8_pad_classes_kernel(int* __restrict__ cls, int To, int Ho, int Wo, int kt, int kh, int kw, int st, int sh, int sw,
-                                      int pt, int ph, int pw, int T, int H, int W) {
-  if (threadIdx.x || blockIdx.x) return;
-  int* c[3] = {cls + 4, cls + 4 + To, cls + 4 + To + Ho};
-  int* m[3] = {cls + 4 + To + Ho + Wo, cls + 4 + 2 * To + Ho + Wo, cls + 4 + 2 * To + 2 * Ho + Wo};
-  const int O[3] = {To, Ho, Wo}, k[3] = {kt, kh, kw}, s[3] = {st, sh, sw}, p[3] = {pt, ph, pw}, I[3] = {T, H, W};
-  for (int d = 0; d < 3; ++d) {
-    int n = 0;
-    for (int o = 0; o < O[d]; ++o) {
-      const int mask = (int)tap_bits(o * s[d] - p[d], k[d], I[d]);
-      int j = 0;
-      while (j < n && m[d][j] != mask) ++j;
-      if (j == n) m[d][n++] = mask;
-      c[d][o] = j;
-    }
-    cls[d] = n;
-  }
-  cls[3] = 0;
-}
-
-__global__ void u8_pad_corr_kernel(const float* __restrict__ wp, const int* __restrict__ cls, float* __restrict__ corr, int cap, int To,
-                                   int Ho, int Wo, int Cin, int kt, int kh, int kw, int Cout, float mean) {
-  const int nt = cls[0], nh = cls[1], nw = cls[2];
-  const int* mt = cls + 4 + To + Ho + Wo;
-  const int* mh = mt + To;
-  const int* mw = mh + Ho;
-  const int total = nt * nh * nw * Cout;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total && idx < cap; idx += gridDim.x * blockDim.x) {
+// corr[ct][ch][cw][n] = -mean * sum of w[k][n] over the taps (dt, dh, dw) inside the clip for border classes (ct, ch, cw)
+__global__ void u8_pad_corr_kernel(const float* __restrict__ wp, float* __restrict__ corr, int total, int Cin, int kt, int kh, int kw,
+                                   int pt, int ph, int pw, int Cout, float mean) {
+  const int nch = (ph + 1) * (ph + 1), ncw = (pw + 1) * (pw + 1);
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int n = idx % Cout, c = idx / Cout;
-    const int wc = c % nw, hc = (c / nw) % nh, tc = c / (nw * nh);
-    const unsigned bt = (unsigned)mt[tc], bh = (unsigned)mh[hc], bw = (unsigned)mw[wc];
+    const int wc = c % ncw, hc = (c / ncw) % nch, tc = c / (ncw * nch);
+    const int t0 = tc / (pt + 1), t1 = kt - tc % (pt + 1), h0 = hc / (ph + 1), h1 = kh - hc % (ph + 1), w0 = wc / (pw + 1), w1 = kw - wc % (pw + 1);
     double sum = 0.0;
-    int k = 0;
     for (int ci = 0; ci < Cin; ++ci)
-      for (int dt = 0; dt < kt; ++dt)
-        for (int dh = 0; dh < kh; ++dh)
-          for (int dw = 0; dw < kw; ++dw, ++k)
-            if ((bt >> dt) & (bh >> dh) & (bw >> dw) & 1u) sum += (double)wp[(size_t)k * Cout + n];
+      for (int dt = t0; dt < t1; ++dt)
+        for (int dh = h0; dh < h1; ++dh)
+          for (int dw = w0; dw < w1; ++dw) sum += (double)wp[(size_t)(((ci * kt + dt) * kh + dh) * kw + dw) * Cout + n];
     corr[idx] = (float)(-(double)mean * sum);
   }
 }
@@ -2199,7 +2225,6 @@ extern "C" int advhip_conv3d_bn_relu_maxpool233_f32(const advhip_conv3d_desc* d,
 
 // ---- stem + maxpool1 straight from resized uint8 frames (TenCrop, float conversion and normalisation in the load stage) ----
 namespace advhip {
-static int u8_class_cap(int O, int k) { return std::min(O, 2 * k + 1); }
 static int u8_check_frames(const advhip_conv3d_desc* d, int64_t F, int FH, int FW) {
   ADVHIP_REQUIRE(F > 0 && F % d->T == 0, "conv3d u8: %lld frames are not whole clips of %d", (long long)F, d->T);
   ADVHIP_REQUIRE(FH >= d->H && FW >= d->W, "conv3d u8: frames (%d x %d) smaller than the %d x %d crop", FH, FW, d->H, d->W);
@@ -2209,41 +2234,40 @@ static int u8_check_frames(const advhip_conv3d_desc* d, int64_t F, int FH, int F
 }
 }  // namespace advhip
 
-extern "C" int advhip_conv3d_u8_table_sizes(const advhip_conv3d_desc* d, int64_t* ktab_ints, int64_t* cls_ints, int64_t* corr_floats) {
+extern "C" int advhip_conv3d_u8_table_sizes(const advhip_conv3d_desc* d, int64_t* ktab_ints, int64_t* corr_floats) {
   if (int rc = validate(d)) return rc;
   const Geometry g = geometry(d);
   if (ktab_ints) *ktab_ints = 4ll * g.Kpad;
-  if (cls_ints) *cls_ints = 4 + 2ll * (g.To + g.Ho + g.Wo);
-  if (corr_floats) *corr_floats = (int64_t)u8_class_cap(g.To, d->kt) * u8_class_cap(g.Ho, d->kh) * u8_class_cap(g.Wo, d->kw) * d->Cout;
+  if (corr_floats) *corr_floats = (int64_t)(d->pt + 1) * (d->pt + 1) * (d->ph + 1) * (d->ph + 1) * (d->pw + 1) * (d->pw + 1) * d->Cout;
   return ADVHIP_OK;
 }
 
 extern "C" int advhip_conv3d_u8_build_tables(const advhip_conv3d_desc* d, int32_t FH, int32_t FW, const float* w_packed, float mean,
-                                             int32_t* ktab_u8, int32_t* cls, float* corr, void* stream) {
+                                             int32_t* ktab_u8, float* corr, void* stream) {
   if (int rc = validate(d)) return rc;
-  ADVHIP_REQUIRE(w_packed && ktab_u8 && cls && corr, "conv3d u8 tables: null pointer");
+  ADVHIP_REQUIRE(w_packed && ktab_u8 && corr, "conv3d u8 tables: null pointer");
   if (int rc = u8_check_frames(d, d->T, FH, FW)) return rc;
   const Geometry g = geometry(d);
-  int64_t cap = 0;
-  advhip_conv3d_u8_table_sizes(d, nullptr, nullptr, &cap);
+  int64_t total = 0;
+  advhip_conv3d_u8_table_sizes(d, nullptr, &total);
+  ADVHIP_REQUIRE(total < (1ll << 28), "conv3d u8 tables: padding (%d,%d,%d) too large", d->pt, d->ph, d->pw);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(build_ktab_u8_kernel, dim3((g.Kpad + 255) / 256), dim3(256), 0, st, reinterpret_cast<int2*>(ktab_u8), d->kt, d->kh,
                      d->kw, d->Cin, g.K, g.Kpad, FW * d->Cin, FH * FW * d->Cin);
-  hipLaunchKernelGGL(u8_pad_classes_kernel, dim3(1), dim3(64), 0, st, cls, g.To, g.Ho, g.Wo, d->kt, d->kh, d->kw, d->st, d->sh, d->sw,
-                     d->pt, d->ph, d->pw, d->T, d->H, d->W);
-  hipLaunchKernelGGL(u8_pad_corr_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, st, w_packed, cls, corr, (int)cap, g.To, g.Ho,
-                     g.Wo, d->Cin, d->kt, d->kh, d->kw, d->Cout, mean);
+  hipLaunchKernelGGL(u8_pad_corr_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, st, w_packed, corr,
+                     (int)total, d->Cin, d->kt, d->kh, d->kw, d->pt, d->ph, d->pw, d->Cout, mean);
   return check_launch("conv3d_u8_build_tables");
 }
 
 extern "C" int advhip_conv3d_u8_tencrop_bn_relu_maxpool233_f32(const advhip_conv3d_desc* d, const uint8_t* frames, int64_t F, int32_t FH,
                                                                int32_t FW, int64_t first_crop_clip, const float* w_packed,
-                                                               const int32_t* ktab_u8, const int32_t* cls, const float* corr,
+                                                               const int32_t* ktab_u8, const float* corr,
                                                                const float* scale, const float* shift, float stdv, float* y,
                                                                int64_t y_batch_stride, void* workspace, int64_t workspace_bytes,
                                                                void* stream) {
   if (int rc = validate(d)) return rc;
-  ADVHIP_REQUIRE(frames && w_packed && ktab_u8 && cls && corr && scale && shift && y, "conv3d u8+pool233: null pointer");
+  ADVHIP_REQUIRE(frames && w_packed && ktab_u8 && corr && scale && shift && y, "conv3d u8+pool233: null pointer");
+  ADVHIP_REQUIRE(d->pt < d->kt && d->ph < d->kh && d->pw < d->kw, "conv3d u8+pool233: padding not smaller than the kernel");
   ADVHIP_REQUIRE(stdv != 0.f, "conv3d u8+pool233: std must be non-zero");
   if (int rc = u8_check_frames(d, F, FH, FW)) return rc;
   ADVHIP_REQUIRE(first_crop_clip >= 0 && first_crop_clip + d->B <= F / d->T * 10,
@@ -2265,7 +2289,7 @@ extern "C" int advhip_conv3d_u8_tencrop_bn_relu_maxpool233_f32(const advhip_conv
   auto half_even = [](int v) { return (v % 2 == 0) ? v / 2 : ((v / 2) % 2 == 0 ? v / 2 : v / 2 + 1); };
   a.u8_ctop = half_even(FH - d->H); a.u8_cleft = half_even(FW - d->W);
   a.in_std = stdv;  // (the mean went into `corr` when the tables were built)
-  a.ktab_u8 = reinterpret_cast<const int2*>(ktab_u8); a.pad_cls = cls; a.pad_corr = corr;
+  a.ktab_u8 = reinterpret_cast<const int2*>(ktab_u8); a.pad_corr = corr;
   // byte offsets: the window origin of a border output lies up to (pt, ph, pw + kw - 1) before the crop's corner
   a.pad_off = (d->pt * FH * FW + d->ph * FW + d->pw + d->kw) * d->Cin;
   a.x_bytes = (unsigned)(F * FH * FW * d->Cin + a.pad_off);

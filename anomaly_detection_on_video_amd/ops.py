@@ -252,15 +252,14 @@ def ensure_u8_tables(pc: "PackedConv", frame_hw: Tuple[int, int], clip_thw: Tupl
     if tabs is None:
         d = pc.desc(1, *clip_thw, True, 0, 1)
         lib = _lib.load()
-        nk, nc, nf = C.c_int64(), C.c_int64(), C.c_int64()
-        check(lib.advhip_conv3d_u8_table_sizes(C.byref(d), C.byref(nk), C.byref(nc), C.byref(nf)), "conv3d_u8_table_sizes")
+        nk, nf = C.c_int64(), C.c_int64()
+        check(lib.advhip_conv3d_u8_table_sizes(C.byref(d), C.byref(nk), C.byref(nf)), "conv3d_u8_table_sizes")
         dev = pc.w_packed.device
         ktab = torch.empty((nk.value,), device=dev, dtype=torch.int32)
-        cls = torch.empty((nc.value,), device=dev, dtype=torch.int32)
         corr = torch.empty((nf.value,), device=dev, dtype=torch.float32)
         check(lib.advhip_conv3d_u8_build_tables(C.byref(d), frame_hw[0], frame_hw[1], ptr(pc.w_packed), C.c_float(mean), ptr(ktab),
-                                                ptr(cls), ptr(corr), stream(dev)), f"conv3d_u8_build_tables[{pc.name}]")
-        tabs = cache[key] = (ktab, cls, corr)
+                                                ptr(corr), stream(dev)), f"conv3d_u8_build_tables[{pc.name}]")
+        tabs = cache[key] = (ktab, corr)
     return tabs
 
 
@@ -289,13 +288,13 @@ def conv3d_u8_tencrop_bn_relu_maxpool233(frames: torch.Tensor, pc: "PackedConv",
     y = out if out is not None else torch.empty(shape, device=frames.device, dtype=torch.float32)
     if tuple(y.shape) != shape or y.dtype != torch.float32 or y.device != frames.device:
         raise ValueError(f"{pc.name}: out {tuple(y.shape)} != {shape}")
-    ktab, cls, corr = ensure_u8_tables(pc, (FH, FW), (frames_per_clip, crop, crop), mean)
+    ktab, corr = ensure_u8_tables(pc, (FH, FW), (frames_per_clip, crop, crop), mean)
     need = lib.advhip_conv3d_relu_maxpool233_workspace_bytes(C.byref(d))
     if need < 0:
         check(int(need), f"conv3d_relu_maxpool233_workspace_bytes[{pc.name}]")
     ws = workspace(frames.device, need)
     check(lib.advhip_conv3d_u8_tencrop_bn_relu_maxpool233_f32(C.byref(d), ptr(frames), F, FH, FW, first, ptr(pc.w_packed), ptr(ktab),
-                                                              ptr(cls), ptr(corr), ptr(pc.scale), ptr(pc.shift),
+                                                              ptr(corr), ptr(pc.scale), ptr(pc.shift),
                                                               C.c_float(std), ptr(y), batch_stride(y), ptr(ws), need, stream()),
           f"conv3d_u8+pool233[{pc.name}]")
     return y

@@ -181,16 +181,17 @@ int advhip_conv3d_bn_relu_maxpool233_f32(const advhip_conv3d_desc* d, const floa
  * (exact in fp32), sum w (pixel - mean) = acc - mean * (sum of the weights of the taps inside the clip) with that sum tabulated
  * per border class, and 1/std is folded into the BN scale: neither the fp32 ten-crop tensor (385 MB per 40 crop-clips) nor
  * the un-pooled stem output exists.
- *   advhip_conv3d_u8_table_sizes: element counts of the three tables below (int32 / int32 / float)
- *   advhip_conv3d_u8_build_tables: ktab_u8 = gather offsets (as stored + mirrored), cls = border classes of every output
- *     t / h / w, corr = -mean * (sum of the weights of the taps inside the clip) per class and channel; once per (weights, FH, FW, clip dims)
+ *   advhip_conv3d_u8_table_sizes: element counts of the two tables below (int32 / float)
+ *   advhip_conv3d_u8_build_tables: ktab_u8 = gather offsets (as stored + mirrored); corr = -mean * (sum of the weights of the
+ *     taps inside the clip) per border class (per dimension: taps before the clip * (p + 1) + taps past its end) and channel;
+ *     once per (weights, FH, FW, clip dims)
  * Result: within fp32 rounding of advhip_tencrop_normalize_u8 + advhip_conv3d_bn_relu_maxpool233_f32 (tests: 2e-5). */
-int advhip_conv3d_u8_table_sizes(const advhip_conv3d_desc* d, int64_t* ktab_ints, int64_t* cls_ints, int64_t* corr_floats);
+int advhip_conv3d_u8_table_sizes(const advhip_conv3d_desc* d, int64_t* ktab_ints, int64_t* corr_floats);
 int advhip_conv3d_u8_build_tables(const advhip_conv3d_desc* d, int32_t FH, int32_t FW, const float* w_packed, float mean,
-                                  int32_t* ktab_u8, int32_t* cls, float* corr, void* stream);
+                                  int32_t* ktab_u8, float* corr, void* stream);
 int advhip_conv3d_u8_tencrop_bn_relu_maxpool233_f32(const advhip_conv3d_desc* d, const uint8_t* frames, int64_t F, int32_t FH,
                                                     int32_t FW, int64_t first_crop_clip, const float* w_packed,
-                                                    const int32_t* ktab_u8, const int32_t* cls, const float* corr,
+                                                    const int32_t* ktab_u8, const float* corr,
                                                     const float* scale, const float* shift, float stdv, float* y,
                                                     int64_t y_batch_stride, void* workspace, int64_t workspace_bytes,
                                                     void* stream);
