@@ -102,6 +102,10 @@ SIGNATURES = {
     "advhip_conv3d_bn_relu_maxpool233_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P]),
     "advhip_conv3d_u8_table_sizes": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "advhip_conv3d_u8_build_tables": (C.c_int, [C.POINTER(ConvDesc), _I, _I, _P, C.c_float, _P, _P, _P]),
+    "advhip_conv3d_u8_taps_table_sizes": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "advhip_conv3d_u8_taps_build_tables": (C.c_int, [C.POINTER(ConvDesc), _I, _I, _P, C.c_float, _P, _P, _P, _P]),
+    "advhip_conv3d_u8_taps_tencrop_bn_relu_maxpool233_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _L, _I, _I, _L, _L, _P, _P, _P, _P, _P,
+                                                                       C.c_float, _P, _L, _P, _L, _P]),
     "advhip_conv3d_u8_tencrop_bn_relu_maxpool233_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _L, _I, _I, _L, _P, _P, _P, _P, _P,
                                                                   C.c_float, _P, _L, _P, _L, _P]),
     "advhip_conv3d_bn_act_maxpool211_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _L, _P, _P, _P, _P, _P, _P, _L, _P]),

@@ -1281,6 +1281,166 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
 }
 
 // ================================================================================================
+// The stem on resized uint8 frames (F, FH, FW, 3), whole pixels at a time.  The byte-gather form above issues one
+// `buffer_load_ubyte ... lds` per (channel, tap) row and 64 positions -- as many LDS-DMA instructions as the fp32 kernel, and
+// the vector issue port those share with the MFMAs is what bounds that kernel (the extra v_cvt of the byte form then costs
+// its full issue time: 2.61 vs 2.43 ms at B = 32).  Here K runs tap-major, channel-minor (k' = tap * 3 + c) and ONE 4-byte
+// LDS-DMA per (tap, position) fetches the pixel's three channel bytes (+ one byte of its neighbour, never used) at the
+// pixel's byte address -- LDS-DMA and ds_read_b128 take byte-granular addresses on gfx950 (tools/probe/): a third of the A
+// loads for the same K.  LDS tile: A [taps][128 positions] pixel dwords, B [3 * taps][64] fp32 weights in k' order.
+// MFMA k-step s of a tile contracts k' = 4 s + lg (lane group lg): tap (4 s + lg) / 3, channel (s + lg) % 3 -- both have
+// period 3 in s, so a lane keeps three LDS addresses (row of its tap + its channel's byte offset: the byte select is part of
+// the address) and v_cvt_f32_ubyte0 of the dword it reads there is its operand.  Epilogue and border-class correction: as
+// the byte form (brick_epilogue<..., EPI_POOL233, true>).
+template <int BKT>  // taps per k-tile
+constexpr int tap_waves_per_simd() {
+  constexpr int ring = 2 * (BKT * 128 + 3 * BKT * 64) * 4, brick = 32 * 132 * 4;
+  constexpr int by_lds = 163840 / (ring > brick ? ring : brick);
+  return by_lds > 6 ? 6 : by_lds;
+}
+
+template <int BKT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(tap_waves_per_simd<BKT>(), 8)))
+void stem_u8_tap_kernel(const ConvArgs a) {
+  constexpr int BM = 128, BN = 64, FM = 4, FN = 2, BKP = 3 * BKT, STEPS = BKP / 4, LA = BKT / 2, NPB = BKP / 4;
+  static_assert(BKT == 8 || BKT == 16, "taps per k-tile");
+  static_assert(STEPS % 3 == 0, "the (tap, channel) pattern of the k-steps has period 3");
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  constexpr int A_FLOATS = BKT * BM, STAGE = A_FLOATS + BKP * BN, RING = 2 * STAGE;
+  constexpr int BRICK_FLOATS = (BN / FN) * (BM + 4);
+  constexpr int SMEM = RING > BRICK_FLOATS ? RING : BRICK_FLOATS;
+  constexpr int BRICK_H = 4, BRICK_W = 16;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile_m = xcd_remap((int)blockIdx.x, a.tiles_m);  // Cout = 64: one n-tile
+  const int ml = tid % BM;
+  const int kr = __builtin_amdgcn_readfirstlane(tid / BM);
+  // m-tile -> (sample, brick t, brick h, brick w); row ml -> position inside the 2 x 4 x 16 brick, w fastest
+  const int bk_b = (int)a.dNb.div((unsigned)tile_m);
+  const int r1 = tile_m - bk_b * (int)a.dNb.d;
+  const int bk_t = (int)a.dNbhw.div((unsigned)r1);
+  const int r2 = r1 - bk_t * (int)a.dNbhw.d;
+  const int bk_h = (int)a.dNbw.div((unsigned)r2);
+  const int bk_w = r2 - bk_h * a.nbw;
+  const int pot = bk_t * 2 + ml / (BRICK_H * BRICK_W), poh = bk_h * BRICK_H + (ml / BRICK_W) % BRICK_H, pow_ = bk_w * BRICK_W + ml % BRICK_W;
+  const int bg = a.u8_first + bk_b, clip = bg / 10, crop = bg - clip * 10, j5 = crop >= 5 ? crop - 5 : crop;
+  const int flip = __builtin_amdgcn_readfirstlane(crop >= 5);
+  unsigned vbase = OOB, vmask = 0;
+  if (pot < a.To && poh < a.Ho && pow_ < a.Wo) {
+    const int it0 = pot * a.st - a.pt, ih0 = poh * a.sh - a.ph, iw0 = pow_ * a.sw - a.pw;
+    const int top = j5 == 4 ? a.u8_ctop : ((j5 >> 1) ? a.u8_FH - a.H : 0), left = j5 == 4 ? a.u8_cleft : ((j5 & 1) ? a.u8_FW - a.W : 0);
+    const int col = flip ? a.u8_FW - 1 - left - iw0 - (a.kw_ - 1) : left + iw0;  // (mirrored crops: see the byte form)
+    vbase = (unsigned)((((clip * a.T + it0) * a.u8_FH + top + ih0) * a.u8_FW + col) * 3 + a.pad_off);
+    vmask = tap_bits(it0, a.kt_, a.T) | (tap_bits(ih0, a.kh_, a.H) << 10) | (tap_bits(iw0, a.kw_, a.W) << 20);
+  }
+  U8Corr u8c{};
+  {
+    const int ot = bk_t * 2 + (wave >> 1), oh = bk_h * BRICK_H + (lane >> 4);
+    const int tc = u8_border_class(ot * a.st - a.pt, a.kt_, a.T, a.pt), hc = u8_border_class(oh * a.sh - a.ph, a.kh_, a.H, a.ph);
+    const int ow0 = bk_w * BRICK_W, owl = ow0 + BRICK_W - 1 < a.Wo ? ow0 + BRICK_W - 1 : a.Wo - 1;
+    const int wc0 = u8_border_class(ow0 * a.sw - a.pw, a.kw_, a.W, a.pw), wc1 = u8_border_class(owl * a.sw - a.pw, a.kw_, a.W, a.pw);
+    const int nch = (a.ph + 1) * (a.ph + 1), ncw = (a.pw + 1) * (a.pw + 1);
+    u8c.row = a.pad_corr + (size_t)((tc * nch + hc) * ncw) * a.Cout + 2 * ((wave & 1) * 16 + (lane & 15));
+    u8c.uniform = wc0 == wc1;
+    u8c.c[0] = u8c.row[(size_t)wc0 * a.Cout];
+    u8c.c[1] = u8c.row[(size_t)wc0 * a.Cout + 1];
+  }
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(const_cast<float*>(a.x)) - a.pad_off, 0, a.x_bytes, 0x00020000);
+  const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+  const int ntaps_pad = a.Kpad / 3;
+  const int2* __restrict__ tab = a.ktab_u8 + (size_t)(flip ? ntaps_pad : 0);
+  const unsigned wvoff = (unsigned)((lane / 16) * BN + (lane % 16) * 4) * 4u;  // B piece: 4 k'-rows x 64 channels = 1 KiB
+  const int a_wave_col = (wave & 1) * 64;
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int DMA_BYTES = 16;  // (the host pass only parses this body; see gemm_kk_dma_kernel)
+#else
+  constexpr int DMA_BYTES = 4;
+#endif
+  int ent[2 * LA];
+  auto issue_tile = [&](int t0, int stage) {  // taps [t0, t0 + BKT) and their 3 * BKT weight rows
+    float* As = smem + stage * STAGE;
+    float* Bs = As + A_FLOATS;
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+      const unsigned voff = ((vmask & (unsigned)ent[2 * j + 1]) == (unsigned)ent[2 * j + 1]) ? vbase : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(As + (kr * LA + j) * BM + a_wave_col), 4, voff, ent[2 * j], 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < (NPB + 3) / 4; ++g) {
+      const int piece = wave + 4 * g;
+      if (piece < NPB)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(Bs + piece * 4 * BN), DMA_BYTES, wvoff, (3 * t0 + 4 * piece) * BN * 4, 0, 0);
+    }
+  };
+
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 15, lg = lane >> 4;
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+  // k-step s = 3 q + t of a tile: this lane's operand is byte (t + lg) % 3 of the pixel dwords of tap row 4 q + (4 t + lg) / 3
+  unsigned a_addr[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) a_addr[t] = lds0 + (unsigned)(((4 * t + lg) / 3) * BM + wm * 64 + FM * li) * 4u + (unsigned)((t + lg) % 3);
+  const unsigned b_addr0 = lds0 + (unsigned)(A_FLOATS + lg * BN + wn * 32 + FN * li) * 4u;
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int jn = 0; jn < FN; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](bool pre, int stage, int pre_t0, int pstage) {
+    const unsigned so = (unsigned)(stage * STAGE) * 4u;
+    Frag<FM> fa[2];
+    Frag<FN> fb[2];
+    if (pre) issue_tile(pre_t0, pstage);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_read<FM, 0>(fa[0], a_addr[0] + so);
+    lds_read<FN, 0>(fb[0], b_addr0 + so);
+    auto body = [&](auto s_c) {
+      constexpr int s = decltype(s_c)::value;
+      if constexpr (s + 1 < STEPS) {
+        lds_read<FM, ((s + 1) / 3) * 4 * BM * 4>(fa[(s + 1) & 1], a_addr[(s + 1) % 3] + so);
+        lds_read<FN, (s + 1) * 4 * BN * 4>(fb[(s + 1) & 1], b_addr0 + so);
+        lds_wait<2>(fa[s & 1], fb[s & 1]);
+      } else {
+        lds_wait<0>(fa[s & 1], fb[s & 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const float e = fa[s & 1].v[i];
+        const float ai = (float)(__builtin_bit_cast(unsigned, e) & 255u);
+#pragma unroll
+        for (int jn = 0; jn < FN; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, fb[s & 1].v[jn], acc[i][jn], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);
+#pragma unroll
+      for (int i = 1; i < FM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x8, FM * FN - (FM - 1), 0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    [&]<int... I>(std::integer_sequence<int, I...>) { (body(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, STEPS>{});
+  };
+
+  const int nt = ntaps_pad / BKT;
+  sload_entries<LA>(tab, (kr * LA) * 8, ent);
+  issue_tile(0, 0);
+  for (int kt = 0; kt < nt; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    const bool pre = kt + 1 < nt;
+    if (pre) sload_entries<LA>(tab, ((kt + 1) * BKT + kr * LA) * 8, ent);
+    compute(pre, kt & 1, (kt + 1) * BKT, (kt + 1) & 1);
+  }
+  __syncthreads();
+  brick_epilogue<BM, BN, 16, EPI_POOL233, true>(a, acc, smem, tile_m, 0, 0, bk_b, bk_t, bk_h, bk_w, wave, lane, tid, u8c);
+}
+
+// ================================================================================================
 // C[s][m][n] = sum_{k in slice s} A[m][k] * B[n][k]: both operands k-contiguous ("NT" product), e.g. the weight gradient
 // dW[o][c] = sum_n dY[o][n] X[c][n] of a GEMM-shaped layer whose activations are stored (channel, position).  Operand
 // tiles are plain row copies [rows][16 k] made by 16-byte LDS-DMA (4 lanes per 64-byte row piece, 16 rows per
@@ -1680,6 +1840,33 @@ __global__ void build_ktab_u8_kernel(int2* __restrict__ tab, int kt, int kh, int
     }
     tab[k] = f;
     tab[Kpad + k] = g;
+  }
+}
+
+// tables of stem_u8_tap_kernel: {byte offset of the tap's pixel, tap bits} for [2][taps_pad] (as stored, mirrored), and the weights
+// re-ordered tap-major: wt[(tap * C + c)][n] = wp[(c * taps + tap)][n], zero rows for the padding taps
+__global__ void build_ktab_u8_taps_kernel(int2* __restrict__ tab, int kt, int kh, int kw, int C, int taps_pad, int FW, int FHW) {
+  const int taps = kt * kh * kw;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < taps_pad; t += gridDim.x * blockDim.x) {
+    int2 f = make_int2(0, (int)(1u << 30)), g = f;
+    if (t < taps) {
+      const int dt = t / (kh * kw), r = t % (kh * kw);
+      const int dh = r / kw, dw = r % kw;
+      const int bits = (int)((1u << dt) | (1u << (10 + dh)) | (1u << (20 + dw)));
+      f = make_int2((dt * FHW + dh * FW + dw) * C, bits);
+      g = make_int2((dt * FHW + dh * FW + (kw - 1 - dw)) * C, bits);
+    }
+    tab[t] = f;
+    tab[taps_pad + t] = g;
+  }
+}
+
+__global__ void pack_weight_taps_kernel(const float* __restrict__ wp, float* __restrict__ wt, int Cout, int C, int taps, int taps_pad) {
+  const long long total = (long long)taps_pad * C * Cout;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % Cout), k = (int)(i / Cout);
+    const int t = k / C, c = k % C;
+    wt[i] = t < taps ? wp[(size_t)(c * taps + t) * Cout + n] : 0.f;
   }
 }
 
@@ -2303,6 +2490,99 @@ extern "C" int advhip_conv3d_u8_tencrop_bn_relu_maxpool233_f32(const advhip_conv
   ADVHIP_REQUIRE(nbw <= MERGE_MAX_NBW, "conv3d u8+pool233: pooled width %d above %d", Wp, MERGE_MAX_NBW * 8 - 1);
   const long long rows = (long long)d->B * a.tiles_n * 2 * Tp * Hp;
   ADVHIP_REQUIRE(rows < (1ll << 31), "conv3d u8+pool233: too many output rows");
+  const unsigned gx = (unsigned)std::min<long long>(rows, 1 << 20), gy = (unsigned)((rows + gx - 1) / gx);
+  hipLaunchKernelGGL(stem_pool_merge_kernel, dim3(gx, gy), dim3(256), (size_t)2 * nbw * 288 * sizeof(float), st, reinterpret_cast<const float*>(workspace), y, d->Cout, Tp,
+                     Hp, Wp, nbh, nbw, a.tiles_n, FastDiv::make((unsigned)Wp), rows, ybs);
+  return check_launch("stem_pool_merge");
+}
+
+// ---- the same from whole pixels (stem_u8_tap_kernel): tables and launch ----------------------------------------------------
+namespace advhip {
+constexpr int U8_TAPS_PER_TILE = 8;
+static int u8_taps_pad(const advhip_conv3d_desc* d) {
+  const int taps = d->kt * d->kh * d->kw;
+  return (taps + U8_TAPS_PER_TILE - 1) / U8_TAPS_PER_TILE * U8_TAPS_PER_TILE;
+}
+}  // namespace advhip
+
+extern "C" int advhip_conv3d_u8_taps_table_sizes(const advhip_conv3d_desc* d, int64_t* ktab_ints, int64_t* corr_floats, int64_t* w_taps_floats) {
+  if (int rc = validate(d)) return rc;
+  if (int rc = advhip_conv3d_u8_table_sizes(d, nullptr, corr_floats)) return rc;
+  const int tp = u8_taps_pad(d);
+  if (ktab_ints) *ktab_ints = 4ll * tp;
+  if (w_taps_floats) *w_taps_floats = (int64_t)tp * d->Cin * d->Cout;
+  return ADVHIP_OK;
+}
+
+extern "C" int advhip_conv3d_u8_taps_build_tables(const advhip_conv3d_desc* d, int32_t FH, int32_t FW, const float* w_packed, float mean,
+                                                  int32_t* ktab_taps, float* corr, float* w_taps, void* stream) {
+  if (int rc = validate(d)) return rc;
+  ADVHIP_REQUIRE(w_packed && ktab_taps && corr && w_taps, "conv3d u8 taps tables: null pointer");
+  ADVHIP_REQUIRE(d->Cin == 3 && d->Cout == 64, "conv3d u8 taps: 3-channel pixels and 64 output channels (Cin=%d, Cout=%d)", d->Cin, d->Cout);
+  if (int rc = u8_check_frames(d, d->T, FH, FW)) return rc;
+  int64_t total = 0;
+  advhip_conv3d_u8_table_sizes(d, nullptr, &total);
+  ADVHIP_REQUIRE(total < (1ll << 28), "conv3d u8 taps tables: padding (%d,%d,%d) too large", d->pt, d->ph, d->pw);
+  const int taps = d->kt * d->kh * d->kw, tp = u8_taps_pad(d);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(build_ktab_u8_taps_kernel, dim3((tp + 255) / 256), dim3(256), 0, st, reinterpret_cast<int2*>(ktab_taps), d->kt, d->kh, d->kw,
+                     d->Cin, tp, FW, FH * FW);
+  hipLaunchKernelGGL(pack_weight_taps_kernel, dim3((unsigned)(((long long)tp * d->Cin * d->Cout + 255) / 256)), dim3(256), 0, st, w_packed, w_taps,
+                     d->Cout, d->Cin, taps, tp);
+  hipLaunchKernelGGL(u8_pad_corr_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, st, w_packed, corr,
+                     (int)total, d->Cin, d->kt, d->kh, d->kw, d->pt, d->ph, d->pw, d->Cout, mean);
+  return check_launch("conv3d_u8_taps_build_tables");
+}
+
+extern "C" int advhip_conv3d_u8_taps_tencrop_bn_relu_maxpool233_f32(const advhip_conv3d_desc* d, const uint8_t* frames, int64_t F, int32_t FH,
+                                                                    int32_t FW, int64_t readable_bytes, int64_t first_crop_clip,
+                                                                    const float* w_taps, const int32_t* ktab_taps, const float* corr,
+                                                                    const float* scale, const float* shift, float stdv, float* y,
+                                                                    int64_t y_batch_stride, void* workspace, int64_t workspace_bytes,
+                                                                    void* stream) {
+  if (int rc = validate(d)) return rc;
+  ADVHIP_REQUIRE(frames && w_taps && ktab_taps && corr && scale && shift && y, "conv3d u8 taps+pool233: null pointer");
+  ADVHIP_REQUIRE(d->Cin == 3 && d->Cout == 64, "conv3d u8 taps+pool233: 3-channel pixels and 64 output channels (Cin=%d, Cout=%d)", d->Cin, d->Cout);
+  ADVHIP_REQUIRE(d->pt < d->kt && d->ph < d->kh && d->pw < d->kw, "conv3d u8 taps+pool233: padding not smaller than the kernel");
+  ADVHIP_REQUIRE(stdv != 0.f, "conv3d u8 taps+pool233: std must be non-zero");
+  if (int rc = u8_check_frames(d, F, FH, FW)) return rc;
+  const int64_t fbytes = F * FH * FW * 3;
+  ADVHIP_REQUIRE(readable_bytes >= fbytes + 1, "conv3d u8 taps+pool233: the frames allocation must extend one byte past the last pixel "
+                 "(pixels are fetched as 4-byte pieces): %lld readable, %lld needed", (long long)readable_bytes, (long long)fbytes + 1);
+  ADVHIP_REQUIRE(first_crop_clip >= 0 && first_crop_clip + d->B <= F / d->T * 10,
+                 "conv3d u8 taps+pool233: crop-clips [%lld, %lld) outside the %lld clips x 10 crops of the frames", (long long)first_crop_clip,
+                 (long long)first_crop_clip + d->B, (long long)(F / d->T));
+  const Geometry g = geometry(d);
+  const int Tp = pool_out(g.To, 2, 2), Hp = pool_out(g.Ho, 3, 2), Wp = pool_out(g.Wo, 3, 2);
+  ADVHIP_REQUIRE(Tp > 0 && Hp > 0 && Wp > 0, "conv3d u8 taps+pool233: conv output (%d,%d,%d) smaller than the (2,3,3) window", g.To, g.Ho, g.Wo);
+  const int64_t need = advhip_conv3d_relu_maxpool233_workspace_bytes(d);
+  ADVHIP_REQUIRE(workspace != nullptr && workspace_bytes >= need && need < 0xF0000000ll,
+                 "conv3d u8 taps+pool233: needs a %lld-byte workspace (got %lld)", (long long)need, (long long)workspace_bytes);
+  const long long y_dense = (long long)d->Cout * Tp * Hp * Wp;
+  const long long ybs = y_batch_stride > 0 ? y_batch_stride : y_dense;
+  ADVHIP_REQUIRE(ybs >= y_dense, "conv3d u8 taps+pool233: y batch stride %lld smaller than one pooled sample (%lld)", ybs, y_dense);
+  ConvArgs a;
+  if (int rc = fill_pool_args(a, d, g, reinterpret_cast<const float*>(frames), 0, w_taps, nullptr, scale, shift, false)) return rc;
+  a.u8_first = (int)first_crop_clip; a.u8_FH = FH; a.u8_FW = FW;
+  auto half_even = [](int v) { return (v % 2 == 0) ? v / 2 : ((v / 2) % 2 == 0 ? v / 2 : v / 2 + 1); };
+  a.u8_ctop = half_even(FH - d->H); a.u8_cleft = half_even(FW - d->W);
+  a.in_std = stdv;
+  a.ktab_u8 = reinterpret_cast<const int2*>(ktab_taps); a.pad_corr = corr;
+  const int tp = u8_taps_pad(d);
+  a.Kpad = 3 * tp;
+  a.w_bytes = (unsigned)((long long)a.Kpad * d->Cout * 4);
+  a.pad_off = (d->pt * FH * FW + d->ph * FW + d->pw + d->kw) * 3;
+  a.x_bytes = (unsigned)(std::min<int64_t>(readable_bytes, fbytes + 4) + a.pad_off);
+  a.y = reinterpret_cast<float*>(workspace);
+  a.y_bstride = 0; a.Tp = Tp; a.relu = 1;
+  const int nbh = (2 * Hp + 1 + 3) / 4, nbw = (2 * Wp + 1 + 15) / 16;
+  set_bricks(a, Tp, nbh, nbw);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((stem_u8_tap_kernel<U8_TAPS_PER_TILE>), dim3((unsigned)a.tiles_m), dim3(256), 0, st, a);
+  if (int rc = check_launch("conv3d u8 taps+pool233")) return rc;
+  ADVHIP_REQUIRE(nbw <= MERGE_MAX_NBW, "conv3d u8 taps+pool233: pooled width %d above %d", Wp, MERGE_MAX_NBW * 8 - 1);
+  const long long rows = (long long)d->B * a.tiles_n * 2 * Tp * Hp;
+  ADVHIP_REQUIRE(rows < (1ll << 31), "conv3d u8 taps+pool233: too many output rows");
   const unsigned gx = (unsigned)std::min<long long>(rows, 1 << 20), gy = (unsigned)((rows + gx - 1) / gx);
   hipLaunchKernelGGL(stem_pool_merge_kernel, dim3(gx, gy), dim3(256), (size_t)2 * nbw * 288 * sizeof(float), st, reinterpret_cast<const float*>(workspace), y, d->Cout, Tp,
                      Hp, Wp, nbh, nbw, a.tiles_n, FastDiv::make((unsigned)Wp), rows, ybs);

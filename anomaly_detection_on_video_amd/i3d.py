@@ -326,7 +326,9 @@ class I3Res50(nn.Module):
         """ensure_tables for forward_frames: every lazily built table, on the current stream, before streams fork."""
         self.ensure_tables((frames_per_clip, crop, crop), batch)
         if self.frames_fused():
-            ops.ensure_u8_tables(self._plan[0].convs[0], tuple(frame_hw), (frames_per_clip, crop, crop))
+            pc = self._plan[0].convs[0]
+            build = ops.ensure_u8_taps_tables if ops.U8_STEM_FORM == "taps" and pc.cin == 3 and pc.cout == 64 else ops.ensure_u8_tables
+            build(pc, tuple(frame_hw), (frames_per_clip, crop, crop))
 
     def forward_frames(self, frames: torch.Tensor, first: int, count: int, frames_per_clip: int = 16, crop: int = 224) -> torch.Tensor:
         """Features (count, 2048, 1, 1, 1) of crop-clips [first, first + count) of a video given as resized uint8 frames

@@ -243,6 +243,42 @@ def conv3d_bn_relu_maxpool233(x: torch.Tensor, pc: PackedConv, out: Optional[tor
 PIXEL_MEAN, PIXEL_STD = 114.75, 57.375  # GroupNormalize constants, src/dataset.py:180-181
 
 
+U8_STEM_FORM = os.environ.get("ADV_U8_STEM", "taps")  # "taps": whole pixels (one 4-byte gather per tap), "bytes": one byte gather per (channel, tap)
+
+
+def readable_bytes(t: torch.Tensor) -> int:
+    """Bytes of the tensor's allocation from its first element on."""
+    return t.untyped_storage().nbytes() - t.storage_offset() * t.element_size()
+
+
+def with_slack(frames: torch.Tensor, slack: int = 4) -> torch.Tensor:
+    """`frames` in an allocation that extends `slack` bytes past its last element (a copy only if it does not already)."""
+    if readable_bytes(frames) >= frames.numel() + slack:
+        return frames
+    buf = torch.empty((frames.numel() + slack,), device=frames.device, dtype=torch.uint8)
+    buf[: frames.numel()].copy_(frames.reshape(-1))
+    return buf[: frames.numel()].view(frames.shape)
+
+
+def ensure_u8_taps_tables(pc: "PackedConv", frame_hw: Tuple[int, int], clip_thw: Tuple[int, int, int], mean: float = PIXEL_MEAN):
+    key = ("taps", tuple(frame_hw), tuple(clip_thw), float(mean))
+    cache = pc.__dict__.setdefault("_u8_tables", {})
+    tabs = cache.get(key)
+    if tabs is None:
+        d = pc.desc(1, *clip_thw, True, 0, 1)
+        lib = _lib.load()
+        nk, nf, nw = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib.advhip_conv3d_u8_taps_table_sizes(C.byref(d), C.byref(nk), C.byref(nf), C.byref(nw)), "conv3d_u8_taps_table_sizes")
+        dev = pc.w_packed.device
+        ktab = torch.empty((nk.value,), device=dev, dtype=torch.int32)
+        corr = torch.empty((nf.value,), device=dev, dtype=torch.float32)
+        wt = torch.empty((nw.value,), device=dev, dtype=torch.float32)
+        check(lib.advhip_conv3d_u8_taps_build_tables(C.byref(d), frame_hw[0], frame_hw[1], ptr(pc.w_packed), C.c_float(mean), ptr(ktab),
+                                                     ptr(corr), ptr(wt), stream(dev)), f"conv3d_u8_taps_build_tables[{pc.name}]")
+        tabs = cache[key] = (ktab, corr, wt)
+    return tabs
+
+
 def ensure_u8_tables(pc: "PackedConv", frame_hw: Tuple[int, int], clip_thw: Tuple[int, int, int], mean: float = PIXEL_MEAN):
     """Gather / border tables of the uint8-frame stem for frames of (FH, FW) and clips of (T, crop, crop); cached on the conv
     (built on the current stream: callers that fork streams build them first, like the other lazily built tables)."""
@@ -288,11 +324,19 @@ def conv3d_u8_tencrop_bn_relu_maxpool233(frames: torch.Tensor, pc: "PackedConv",
     y = out if out is not None else torch.empty(shape, device=frames.device, dtype=torch.float32)
     if tuple(y.shape) != shape or y.dtype != torch.float32 or y.device != frames.device:
         raise ValueError(f"{pc.name}: out {tuple(y.shape)} != {shape}")
-    ktab, corr = ensure_u8_tables(pc, (FH, FW), (frames_per_clip, crop, crop), mean)
     need = lib.advhip_conv3d_relu_maxpool233_workspace_bytes(C.byref(d))
     if need < 0:
         check(int(need), f"conv3d_relu_maxpool233_workspace_bytes[{pc.name}]")
     ws = workspace(frames.device, need)
+    if U8_STEM_FORM == "taps" and pc.cin == 3 and pc.cout == 64:
+        frames = with_slack(frames)
+        ktab, corr, wt = ensure_u8_taps_tables(pc, (FH, FW), (frames_per_clip, crop, crop), mean)
+        check(lib.advhip_conv3d_u8_taps_tencrop_bn_relu_maxpool233_f32(C.byref(d), ptr(frames), F, FH, FW, readable_bytes(frames), first, ptr(wt),
+                                                                       ptr(ktab), ptr(corr), ptr(pc.scale), ptr(pc.shift), C.c_float(std),
+                                                                       ptr(y), batch_stride(y), ptr(ws), need, stream()),
+              f"conv3d_u8_taps+pool233[{pc.name}]")
+        return y
+    ktab, corr = ensure_u8_tables(pc, (FH, FW), (frames_per_clip, crop, crop), mean)
     check(lib.advhip_conv3d_u8_tencrop_bn_relu_maxpool233_f32(C.byref(d), ptr(frames), F, FH, FW, first, ptr(pc.w_packed), ptr(ktab),
                                                               ptr(corr), ptr(pc.scale), ptr(pc.shift),
                                                               C.c_float(std), ptr(y), batch_stride(y), ptr(ws), need, stream()),

@@ -196,6 +196,21 @@ int advhip_conv3d_u8_tencrop_bn_relu_maxpool233_f32(const advhip_conv3d_desc* d,
                                                     int64_t y_batch_stride, void* workspace, int64_t workspace_bytes,
                                                     void* stream);
 
+/* The same stem from WHOLE PIXELS: K runs tap-major (k' = tap * 3 + c), one 4-byte LDS-DMA per (tap, position) fetches the
+ * pixel's three channel bytes at the pixel's byte address (a third of the gather instructions of the byte form for the same
+ * K; LDS-DMA and ds_read take byte-granular addresses on gfx950), the byte select is part of the LDS read address.  Cin = 3,
+ * Cout = 64.  `readable_bytes`: bytes readable from `frames` on; must be >= F*FH*FW*3 + 1 (the last pixel's 4-byte piece).
+ *   w_taps: the weights re-ordered tap-major (built from w_packed), ktab_taps: pixel offsets per tap (as stored + mirrored). */
+int advhip_conv3d_u8_taps_table_sizes(const advhip_conv3d_desc* d, int64_t* ktab_ints, int64_t* corr_floats, int64_t* w_taps_floats);
+int advhip_conv3d_u8_taps_build_tables(const advhip_conv3d_desc* d, int32_t FH, int32_t FW, const float* w_packed, float mean,
+                                       int32_t* ktab_taps, float* corr, float* w_taps, void* stream);
+int advhip_conv3d_u8_taps_tencrop_bn_relu_maxpool233_f32(const advhip_conv3d_desc* d, const uint8_t* frames, int64_t F, int32_t FH,
+                                                         int32_t FW, int64_t readable_bytes, int64_t first_crop_clip,
+                                                         const float* w_taps, const int32_t* ktab_taps, const float* corr,
+                                                         const float* scale, const float* shift, float stdv, float* y,
+                                                         int64_t y_batch_stride, void* workspace, int64_t workspace_bytes,
+                                                         void* stream);
+
 /* y = MaxPool3d(k=(2,1,1), s=(2,1,1))( act( conv3d(x, w) * scale + shift (+ residual) ) ) for a 1x1x1 stride-1 conv
  * (Cin a multiple of 32) in ONE launch: the last Bottleneck of layer1 followed by maxpool2 (src/i3d.py:111-121, 309).
  * Each m-tile holds both frames of a pooling pair, so the pooling is exact inside the epilogue: the un-pooled

@@ -51,8 +51,17 @@ CASES = [
 ]
 
 
+@pytest.fixture(params=["taps", "bytes"])
+def form(request, monkeypatch):
+    """Both uint8 stems: whole pixels per gather (the default) and one byte per (channel, tap)."""
+    from anomaly_detection_on_video_amd import ops
+
+    monkeypatch.setattr(ops, "U8_STEM_FORM", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("case", CASES, ids=[str(c[0]) + f"/{c[1]}/{c[2]}" for c in CASES])
-def test_u8_stem_matches_float_pipeline_and_oracle(case):
+def test_u8_stem_matches_float_pipeline_and_oracle(case, form):
     from anomaly_detection_on_video_amd import mil_ops, ops
     from oracle import host_oracle, i3d_oracle
 
@@ -79,7 +88,7 @@ def test_u8_stem_matches_float_pipeline_and_oracle(case):
         assert_close_elementwise(got.cpu(), want)
 
 
-def test_u8_stem_constant_frames_hit_only_the_border_table():
+def test_u8_stem_constant_frames_hit_only_the_border_table(form):
     """All pixels = 115 -> (pixel - mean) = 0.25 everywhere: interior outputs are 0.25 * sum(w) and the border outputs differ
     from them only through the taps outside the clip -- a direct check of the per-class correction (a missing correction
     would be off by 114.75 * the outside weights, ~100x the signal)."""
@@ -92,7 +101,7 @@ def test_u8_stem_constant_frames_hit_only_the_border_table():
     assert float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
 
 
-def test_u8_stem_writes_into_a_channel_slice_and_rejects_bad_ranges():
+def test_u8_stem_writes_into_a_channel_slice_and_rejects_bad_ranges(form):
     from anomaly_detection_on_video_amd import ops
 
     pc, _ = _stem()
@@ -109,7 +118,7 @@ def test_u8_stem_writes_into_a_channel_slice_and_rejects_bad_ranges():
         ops.conv3d_u8_tencrop_bn_relu_maxpool233(fd, pc, 0, 5, 8, 64)       # crop larger than the frame
 
 
-def test_forward_frames_whole_backbone_and_fallback(monkeypatch):
+def test_forward_frames_whole_backbone_and_fallback(form):
     """I3Res50.forward_frames (uint8 frames -> features) vs forward_single on the fp32 ten-crop tensor: 40 crop-clips of the
     reference's geometry in the chunks the extraction driver uses, and the separate-pass fallback when the pools are not fused."""
     from anomaly_detection_on_video_amd import mil_ops

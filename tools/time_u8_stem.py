@@ -17,7 +17,7 @@ m = m.eval().to(dev)
 m.prepare()
 pc = m._plan[0].convs[0]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-fr = torch.randint(0, 256, (64, 256, 340, 3), dtype=torch.uint8, device=dev)
+fr = ops.with_slack(torch.randint(0, 256, (64, 256, 340, 3), dtype=torch.uint8, device=dev))
 x = mil_ops.tencrop_normalize_u8(fr)[:B].contiguous()
 
 
@@ -37,6 +37,6 @@ def t(fn, n=20):
 gf = 2 * 4720.6e6 * B / 1e12
 for name, fn in [("tencrop_normalize_u8 (40 crop-clips)", lambda: mil_ops.tencrop_normalize_u8(fr)),
                  ("stem+pool from fp32 crops", lambda: ops.conv3d_bn_relu_maxpool233(x, pc)),
-                 ("stem+pool from uint8 frames", lambda: ops.conv3d_u8_tencrop_bn_relu_maxpool233(fr, pc, 0, B))]:
+                 ("stem+pool from uint8 frames (" + ops.U8_STEM_FORM + ")", lambda: ops.conv3d_u8_tencrop_bn_relu_maxpool233(fr, pc, 0, B))]:
     us = t(fn)
     print(f"B={B} {name:40s} {us:9.1f} us" + (f"  {gf / us * 1e6:6.1f} TFLOP/s" if "stem" in name else ""), flush=True)
