@@ -68,6 +68,11 @@ __host__ __device__ __forceinline__ int u8_border_class(int c0, int k, int n, in
   return (lo > p ? p : lo) * (p + 1) + hi;
 }
 
+// byte 0 of an LDS dword (as it arrives in a float register) -> its value as fp32: one v_cvt_f32_ubyte0.  Every vector
+// instruction beside the MFMAs costs this loop its issue time; the two-instruction exact alternative ((2^23 + b) - 2^23:
+// v_or_b32_sdwa + v_add_f32) measured 2.60 ms against 2.50 ms for the stem at B = 32
+__device__ __forceinline__ float u8_to_f32(float raw) { return (float)(__builtin_bit_cast(unsigned, raw) & 255u); }
+
 struct ConvArgs {
   const float* x;
   const float* w;     // [Kpad][Cout]
@@ -1149,7 +1154,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
         const float e = f.v[i];
-        cv[i] = (float)(__builtin_bit_cast(unsigned, e) & 255u);
+        cv[i] = u8_to_f32(e);
       }
       f.v = cv;
     };
@@ -1183,7 +1188,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks & 1].v[i], fb[ks & 1].v[j], acc[i][j], 0, 0, 0);
         if constexpr (ks + 1 < KS) {
 #pragma unroll
-          for (int i = 0; i < FM; ++i) {  // one MFMA, one cvt of the next step beside it
+          for (int i = 0; i < FM; ++i) {  // one MFMA, one conversion of the next step beside it
             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);
           }
@@ -1410,14 +1415,14 @@ void stem_u8_tap_kernel(const ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
         const float e = fa[s & 1].v[i];
-        const float ai = (float)(__builtin_bit_cast(unsigned, e) & 255u);
+        const float ai = u8_to_f32(e);
 #pragma unroll
         for (int jn = 0; jn < FN; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, fb[s & 1].v[jn], acc[i][jn], 0, 0, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);  // operand 0's conversion
 #pragma unroll
       for (int i = 1; i < FM; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);  // one MFMA, the next operand's conversion beside it
         __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);
       }
       __builtin_amdgcn_sched_group_barrier(0x8, FM * FN - (FM - 1), 0);
