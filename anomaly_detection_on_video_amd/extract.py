@@ -141,7 +141,13 @@ def extract_video_frames(model, frames: torch.Tensor, frames_per_clip: int = FRA
     max_cc = kw.get("max_crop_clips", 32)
     direct = hasattr(model, "forward_frames") and hasattr(model, "frames_fused") and model.frames_fused()
     for f0 in range(0, frames.shape[0], step):
-        fr = frames[f0 : f0 + step].to(dev, non_blocking=True)
+        fr = frames[f0 : f0 + step]
+        if direct and not fr.is_cuda:  # a device buffer with a few spare bytes behind the pixels (the stem fetches whole 4-byte pieces)
+            buf = torch.empty((fr.numel() + 16,), device=dev, dtype=torch.uint8)
+            buf[: fr.numel()].copy_(fr.reshape(-1), non_blocking=True)
+            fr = buf[: fr.numel()].view(fr.shape)
+        else:
+            fr = fr.to(dev, non_blocking=True)
         if not direct:
             x = mil_ops.tencrop_normalize_u8(fr, frames_per_clip, crop)
             rows.append(run_chunks_on_lanes(model, [x[i : i + max_cc] for i in range(0, x.shape[0], max_cc)]))

@@ -138,3 +138,39 @@ def test_forward_frames_whole_backbone_and_fallback(form):
     m.fuse_pool = False
     assert not m.frames_fused()
     assert torch.equal(m.forward_frames(fd, 5, 4), m(mil_ops.tencrop_normalize_u8(fd, 16, 224)[5:9]))
+
+
+def test_stream_steps_from_frames_match_steps_from_crops(form):
+    """ExtractScoreStream on three lanes fed with FrameCrops (uint8 frames, H2D copy inside the step's `prepare`) vs the same
+    steps fed with the fp32 ten-crop tensor: features within 1e-5, first step on every lane equal to a later one bit for bit
+    (the lazily built tables are ordered before the lanes that read them), same videos scored."""
+    from anomaly_detection_on_video_amd import mil_ops
+    from anomaly_detection_on_video_amd.i3d import I3Res50
+    from anomaly_detection_on_video_amd.models.mgfn import MGFNConfig, MGFNForVideoAnomalyDetection
+    from anomaly_detection_on_video_amd.pipeline import ExtractScoreStream, FrameCrops
+    from anomaly_detection_on_video_amd.weights import synth_i3d_state_dict, synth_module_state_dict
+
+    dev = _dev()
+    sc = MGFNForVideoAnomalyDetection(MGFNConfig())
+    sc.load_state_dict(synth_module_state_dict(sc))
+    sc = sc.eval().to(dev)
+
+    def fresh():
+        m = I3Res50()
+        m.load_state_dict(synth_i3d_state_dict())
+        return m.eval().to(dev)
+
+    host = torch.from_numpy(_frames(21, (32, 256, 340, 3))).pin_memory()  # 2 clips = 20 crop-clips per step
+    a = ExtractScoreStream(fresh(), sc, clips_per_video=4, ncrops=10, local_batch=20)
+    ha = [a.step_async(host, prepare=lambda h: FrameCrops(h.to(dev, non_blocking=True), 0, 20)) for _ in range(6)]
+    a.drain()
+    fa = [h.result()[0].cpu() for h in ha]
+    b = ExtractScoreStream(fresh(), sc, clips_per_video=4, ncrops=10, local_batch=20)
+    hb = [b.step_async(host, prepare=lambda h: mil_ops.tencrop_normalize_u8(h.to(dev, non_blocking=True))) for _ in range(6)]
+    b.drain()
+    fb = [h.result()[0].cpu() for h in hb]
+    torch.cuda.synchronize()
+    for i in range(6):
+        assert rel_err(fa[i], fb[i]) < 1e-5, f"step {i}"
+        assert torch.equal(fa[i], fa[(i + 3) % 6])
+    assert a.videos_scored == b.videos_scored == 3  # 6 steps x 2 clips = 12 clips = 3 videos of 4
