@@ -61,6 +61,38 @@ def test_capi_argument_validation_without_gpu():
     assert lib.advhip_maxpool3d_f32(None, None, 1, 1, 2, 3, 3, 2, 3, 3, 2, 2, 2, None) == -1
 
 
+def test_u8_stem_entry_points_validate_before_any_launch():
+    """The uint8-frame stem: table sizes are pure host arithmetic, and bad frames / ranges / slack are refused with a message
+    (every call below fails validation, so nothing is launched; the pointers are never dereferenced on the host)."""
+    import ctypes as C
+
+    from anomaly_detection_on_video_amd import _lib
+
+    lib = _lib.load()
+    stem = _lib.ConvDesc(8, 3, 16, 224, 224, 64, 5, 7, 7, 2, 2, 2, 2, 3, 3, 1, 0, 0)
+    nk, nf, nw = C.c_int64(), C.c_int64(), C.c_int64()
+    assert lib.advhip_conv3d_u8_table_sizes(C.byref(stem), C.byref(nk), C.byref(nf)) == 0
+    assert (nk.value, nf.value) == (4 * 736, 9 * 16 * 16 * 64)   # two {offset, bits} tables; (pt+1)^2 (ph+1)^2 (pw+1)^2 classes x Cout
+    assert lib.advhip_conv3d_u8_taps_table_sizes(C.byref(stem), C.byref(nk), C.byref(nf), C.byref(nw)) == 0
+    assert (nk.value, nw.value) == (4 * 248, 248 * 3 * 64)        # 245 taps -> 248 (k-tiles of 8 taps)
+    p = C.c_void_p(4096)  # stands for a device pointer
+    F, FH, FW = 32, 256, 340
+    nbytes = F * FH * FW * 3
+    args = lambda d, frames_F, readable, first: (C.byref(d), p, frames_F, FH, FW, readable, first, p, p, p, p, p, C.c_float(57.375), p, 0, p, 1 << 40, None)
+    assert lib.advhip_conv3d_u8_taps_tencrop_bn_relu_maxpool233_f32(*args(stem, F, nbytes, 0)) == -1
+    assert b"one byte past the last pixel" in lib.advhip_last_error()
+    assert lib.advhip_conv3d_u8_taps_tencrop_bn_relu_maxpool233_f32(*args(stem, F, nbytes + 4, 13)) == -1
+    assert b"outside the 2 clips x 10 crops" in lib.advhip_last_error()
+    assert lib.advhip_conv3d_u8_taps_tencrop_bn_relu_maxpool233_f32(*args(stem, F - 1, nbytes + 4, 0)) == -1
+    assert b"not whole clips" in lib.advhip_last_error()
+    wide = _lib.ConvDesc(8, 4, 16, 224, 224, 64, 5, 7, 7, 2, 2, 2, 2, 3, 3, 1, 0, 0)
+    assert lib.advhip_conv3d_u8_taps_tencrop_bn_relu_maxpool233_f32(*args(wide, F, nbytes + 4, 0)) == -1
+    assert b"3-channel pixels" in lib.advhip_last_error()
+    big = _lib.ConvDesc(8, 3, 16, 300, 224, 64, 5, 7, 7, 2, 2, 2, 2, 3, 3, 1, 0, 0)
+    assert lib.advhip_conv3d_u8_tencrop_bn_relu_maxpool233_f32(C.byref(big), p, F, FH, FW, 0, p, p, p, p, p, C.c_float(57.375), p, 0, p, 1 << 40, None) == -1
+    assert b"smaller than the 300 x 224 crop" in lib.advhip_last_error()
+
+
 def test_uninstantiated_algo_ids_are_rejected_without_gpu():
     """Ids inside a family's numeric range that have no kernel (DMA 69, DMA4 97/101-104, split-bf16 129-132/135/136,
     DMA2 165, and anything outside every family) must be an error, never a silent no-op (host-side query only)."""
