@@ -56,7 +56,10 @@ class ExtractScoreStream:
         self.lanes = int(os.environ.get("ADV_PIPELINE_LANES", "3"))
         self._lane_streams: List[torch.cuda.Stream] = []
         self._lane_next = 0
-        self._ordered: Optional[torch.cuda.Event] = None  # end of the previous step's gather + ingest
+        self._ordered: Optional[torch.cuda.Event] = None  # the previous step's gather + ring update (+ its scoring's ring reads)
+        self._scored_done: Optional[torch.cuda.Event] = None  # end of the last scoring
+        self._last_done: Optional[torch.cuda.Event] = None    # end of the last step issued
+        self._after_ring_read = None                           # step_async: hook run once a scoring has issued its ring reads
         self._table_dims: set = set()                      # (batch, T, H, W) whose lazily built operands exist
         self._tables_built: Optional[torch.cuda.Event] = None
 
@@ -134,16 +137,41 @@ class ExtractScoreStream:
             if self._ordered is not None:
                 lane.wait_event(self._ordered)
             gathered = adist.all_gather_rows(feats) if self.world > 1 else feats
-            scored = self.ingest(gathered)
-            self._ordered = torch.cuda.Event()
-            self._ordered.record(lane)
-        return StepHandle(self._ordered, gathered, scored)
+
+            # The ring update is what has to run step after step.  A video's scoring (2.5 ms of small launches every
+            # clips_per_video * ncrops / global_batch steps) only READS its ring rows at its very start (add_magnitude /
+            # the copy into the graph's input): the next step may touch the ring as soon as that read is issued, so the
+            # `_ordered` event is recorded there and the scorer runs beside the other lanes' steps instead of holding
+            # them up (with the event at the end of the scoring every lane queued behind it: -2 % clips/s).
+            fired = []
+
+            def ring_read():  # (called when the LAST video of this batch has issued its ring reads)
+                self._ordered = torch.cuda.Event()
+                self._ordered.record(lane)
+                fired.append(True)
+                if self._scored_done is not None:  # scorings themselves stay ordered (lazily built operand caches)
+                    lane.wait_event(self._scored_done)
+
+            self._after_ring_read = ring_read
+            try:
+                scored = self.ingest(gathered)
+            finally:
+                self._after_ring_read = None
+            done = torch.cuda.Event()
+            done.record(lane)
+            if scored:
+                self._scored_done = done
+            if not fired:
+                self._ordered = done
+        self._last_done = done
+        return StepHandle(done, gathered, scored)
 
     def drain(self) -> None:
         """Make the caller's current stream wait for every step issued by step_async."""
         cur = torch.cuda.current_stream(self.ring.device)
-        if self._ordered is not None:
-            cur.wait_event(self._ordered)
+        for ev in (self._ordered, self._scored_done, self._last_done):
+            if ev is not None:
+                cur.wait_event(ev)
 
     @torch.no_grad()
     def ingest(self, gathered: torch.Tensor) -> List[Tuple[int, torch.Tensor]]:
@@ -156,11 +184,13 @@ class ExtractScoreStream:
         first_done = self.pos // self.per_video  # videos complete before this batch
         self.pos += self.global_batch
         scored = []
-        for v in range(first_done, self.pos // self.per_video):
-            if v % self.world != self.rank:
-                continue
+        mine = [v for v in range(first_done, self.pos // self.per_video) if v % self.world == self.rank]
+        hook, self._after_ring_read = self._after_ring_read, None
+        for v in mine:
             r0 = (v * self.per_video) % self.ring_rows
             vid = self.ring[r0 : r0 + self.per_video].view(self.clips_per_video, self.ncrops, -1)
+            if v == mine[-1]:
+                self._after_ring_read = hook  # the ring is free for the next step once the last video has been read
             scored.append((v, self.score_video(vid)))
         return scored
 
@@ -182,14 +212,22 @@ class ExtractScoreStream:
                 entry = self._graphs[key] = (graph, static_in, static_out)
             graph, static_in, static_out = entry
             static_in.copy_(feats)
+            self._ring_read_issued()
             graph.replay()
             self.last_scores = static_out.clone()
         else:
-            self.last_scores = self._score_eager(feats)
+            self.last_scores = self._score_eager(feats, self._ring_read_issued)
         return self.last_scores
 
-    def _score_eager(self, feats: torch.Tensor) -> torch.Tensor:
-        x = mil_ops.add_magnitude(feats)  # (T, 10, 2049)
+    def _ring_read_issued(self) -> None:
+        if self._after_ring_read is not None:
+            hook, self._after_ring_read = self._after_ring_read, None
+            hook()
+
+    def _score_eager(self, feats: torch.Tensor, after_read=None) -> torch.Tensor:
+        x = mil_ops.add_magnitude(feats)  # (T, 10, 2049): the only read of `feats` (ring rows)
+        if after_read is not None:
+            after_read()
         video = x.unsqueeze(0).permute(0, 2, 1, 3).contiguous()
         return self.scorer(video=video).scores.reshape(-1)
 
