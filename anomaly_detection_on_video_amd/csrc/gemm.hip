@@ -245,48 +245,9 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   for (int i = lane; i < n; i += 64) q[i] = expf(p[i] * scale - mx) * inv;
 }
 
-// Per-position statistics over the channels of a (C, N) activation (MGFNLayerNorm, modeling_mgfn.py:36-46):
-// mu[n] = mean_c x[c, n], rs[n] = 1 / (sqrt(var_biased_c x[c, n]) + eps).  Threads run along n (coalesced rows); a block's 4
-// waves split the channels and combine through LDS (mean first, then the centred second moment: two passes, x is L2-warm).
-__global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict__ x, float* __restrict__ mu, float* __restrict__ rs,
-                                                         int Cc, long long N, float eps) {
-  __shared__ float part[4][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long long n = blockIdx.x * 64ll + lane;
-  const bool ok = n < N;
-  float s = 0.f;
-  if (ok)
-    for (int c = w; c < Cc; c += 4) s += x[(long long)c * N + n];
-  part[w][lane] = s;
-  __syncthreads();
-  const float mean = (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]) / (float)Cc;
-  __syncthreads();
-  float q = 0.f;
-  if (ok)
-    for (int c = w; c < Cc; c += 4) {
-      const float d = x[(long long)c * N + n] - mean;
-      q += d * d;
-    }
-  part[w][lane] = q;
-  __syncthreads();
-  if (w == 0 && ok) {
-    const float var = (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]) / (float)Cc;
-    mu[n] = mean;
-    rs[n] = 1.f / (sqrtf(var) + eps);
-  }
-}
-
 }  // namespace advhip
 
 using namespace advhip;
-
-extern "C" int advhip_chan_stats_f32(const float* x, float* mu, float* rs, int32_t C, int64_t N, float eps, void* stream) {
-  ADVHIP_REQUIRE(x && mu && rs && C > 0 && N > 0, "chan_stats: bad arguments");
-  const long long blocks = (N + 63) / 64;
-  ADVHIP_REQUIRE(blocks < (1ll << 31), "chan_stats: too many positions");
-  hipLaunchKernelGGL(chan_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, mu, rs, C, (long long)N, eps);
-  return check_launch("chan_stats");
-}
 
 extern "C" int advhip_bgemm_f32(const advhip_gemm_desc* d, const float* A, const float* B, float* C, void* stream) {
   ADVHIP_REQUIRE(d && A && B && C, "bgemm: null pointer");

@@ -12,83 +12,164 @@
 
 namespace advhip {
 
-constexpr int LN_COLS = 64;  // positions per block (one per lane); the block's 4 waves split the channels
+// A block = LN_COLS positions x LN_GROUPS channel groups (512 threads): lanes run along n (128-byte row pieces), the channel
+// groups split C and combine through LDS.  N = 10240 positions give 320 blocks (64-position blocks: 160 for 256 CUs) and
+// the channel loops are unrolled eight-fold -- these kernels live on bytes in flight (round 2: 42 / 68 us fwd / bwd at
+// 1024 x 10240 with 64 positions x 4 waves, ~2 TB/s).
+constexpr int LN_COLS = 32, LN_GROUPS = 16, LN_THREADS = LN_COLS * LN_GROUPS, LN_UNROLL = 8;
+
+// per-position mean and 1 / (std_biased + eps) of x[:, n] in one read: sums of d = x - x[0, n] and d^2 (the shift keeps
+// s2 / C - (s1 / C)^2 free of cancellation: d is of the order of the spread, whatever the mean)
+__device__ __forceinline__ void ln_stats(const float* __restrict__ x, int Cc, long long N, long long n, bool ok, int p, int grp,
+                                         float (*part)[LN_GROUPS][LN_COLS], float eps, float& mean, float& r) {
+  const float x0 = ok ? x[n] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  if (ok) {
+    int c = grp;
+    for (; c + (LN_UNROLL - 1) * LN_GROUPS < Cc; c += LN_UNROLL * LN_GROUPS) {
+      float v[LN_UNROLL];
+#pragma unroll
+      for (int u = 0; u < LN_UNROLL; ++u) v[u] = x[(long long)(c + u * LN_GROUPS) * N + n];
+#pragma unroll
+      for (int u = 0; u < LN_UNROLL; ++u) {
+        const float d = v[u] - x0;
+        s1 += d;
+        s2 += d * d;
+      }
+    }
+    for (; c < Cc; c += LN_GROUPS) {
+      const float d = x[(long long)c * N + n] - x0;
+      s1 += d;
+      s2 += d * d;
+    }
+  }
+  part[0][grp][p] = s1;
+  part[1][grp][p] = s2;
+  __syncthreads();
+  float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+  for (int gI = 0; gI < LN_GROUPS; ++gI) {  // fixed order: deterministic
+    t1 += part[0][gI][p];
+    t2 += part[1][gI][p];
+  }
+  const float m1 = t1 / (float)Cc;
+  mean = x0 + m1;
+  const float var = fmaxf(t2 / (float)Cc - m1 * m1, 0.f);
+  r = 1.f / (sqrtf(var) + eps);
+}
+
+// mu[n] = mean_c x[c, n], rs[n] = 1 / (sqrt(var_biased_c x[c, n]) + eps) alone (the LayerNorm folded into a GEMM epilogue)
+__global__ __launch_bounds__(LN_THREADS) void chan_stats_kernel(const float* __restrict__ x, float* __restrict__ mu, float* __restrict__ rs,
+                                                                int Cc, long long N, float eps) {
+  __shared__ float part[2][LN_GROUPS][LN_COLS];
+  const int p = threadIdx.x % LN_COLS, grp = threadIdx.x / LN_COLS;
+  const long long n = blockIdx.x * (long long)LN_COLS + p;
+  const bool ok = n < N;
+  float mean, r;
+  ln_stats(x, Cc, N, n, ok, p, grp, part, eps, mean, r);
+  if (ok && grp == 0) { mu[n] = mean; rs[n] = r; }
+}
 
 // y = (x - mu) * rs * g + b;  mu / rs per position are outputs too (saved for the backward pass)
-__global__ __launch_bounds__(256) void chan_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                                 const float* __restrict__ b, float* __restrict__ y,
-                                                                 float* __restrict__ mu, float* __restrict__ rs, int Cc, long long N,
-                                                                 float eps) {
-  __shared__ float part[4][LN_COLS];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long long n = blockIdx.x * (long long)LN_COLS + lane;
+__global__ __launch_bounds__(LN_THREADS) void chan_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                        const float* __restrict__ b, float* __restrict__ y,
+                                                                        float* __restrict__ mu, float* __restrict__ rs, int Cc, long long N,
+                                                                        float eps) {
+  __shared__ float part[2][LN_GROUPS][LN_COLS];
+  const int p = threadIdx.x % LN_COLS, grp = threadIdx.x / LN_COLS;
+  const long long n = blockIdx.x * (long long)LN_COLS + p;
   const bool ok = n < N;
-  float s = 0.f;
-  if (ok)
-    for (int c = w; c < Cc; c += 4) s += x[(long long)c * N + n];
-  part[w][lane] = s;
-  __syncthreads();
-  const float mean = (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]) / (float)Cc;
-  __syncthreads();
-  float q = 0.f;
-  if (ok)
-    for (int c = w; c < Cc; c += 4) {
-      const float d = x[(long long)c * N + n] - mean;
-      q += d * d;
-    }
-  part[w][lane] = q;
-  __syncthreads();
-  const float var = (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]) / (float)Cc;
-  const float r = 1.f / (sqrtf(var) + eps);
+  float mean, r;
+  ln_stats(x, Cc, N, n, ok, p, grp, part, eps, mean, r);
   if (!ok) return;
-  if (w == 0) { mu[n] = mean; rs[n] = r; }
-  for (int c = w; c < Cc; c += 4) y[(long long)c * N + n] = (x[(long long)c * N + n] - mean) * r * g[c] + b[c];
+  if (grp == 0) { mu[n] = mean; rs[n] = r; }
+  int c = grp;
+  for (; c + (LN_UNROLL - 1) * LN_GROUPS < Cc; c += LN_UNROLL * LN_GROUPS) {
+    float v[LN_UNROLL];
+#pragma unroll
+    for (int u = 0; u < LN_UNROLL; ++u) v[u] = x[(long long)(c + u * LN_GROUPS) * N + n];
+#pragma unroll
+    for (int u = 0; u < LN_UNROLL; ++u) {
+      const int cc = c + u * LN_GROUPS;
+      y[(long long)cc * N + n] = (v[u] - mean) * r * g[cc] + b[cc];
+    }
+  }
+  for (; c < Cc; c += LN_GROUPS) y[(long long)c * N + n] = (x[(long long)c * N + n] - mean) * r * g[c] + b[c];
 }
 
 // With xc = x - mu, r = rs, sigma = 1/r - eps, dyg = dy * g:
 //   dx = r * (dyg - mean_c(dyg)) - r^2 / sigma * mean_c(dyg * xc) * xc
 //   dg[c] = sum_n dy * xc * r,  db[c] = sum_n dy        (written as per-block partial sums pg / pb [blocks][C])
-__global__ __launch_bounds__(256) void chan_layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                                 const float* __restrict__ g, const float* __restrict__ mu,
-                                                                 const float* __restrict__ rs, float* __restrict__ dx,
-                                                                 float* __restrict__ pg, float* __restrict__ pb, int Cc, long long N,
-                                                                 float eps) {
-  __shared__ float part[2][4][LN_COLS];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long long n = blockIdx.x * (long long)LN_COLS + lane;
+__global__ __launch_bounds__(LN_THREADS) void chan_layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                        const float* __restrict__ g, const float* __restrict__ mu,
+                                                                        const float* __restrict__ rs, float* __restrict__ dx,
+                                                                        float* __restrict__ pg, float* __restrict__ pb, int Cc, long long N,
+                                                                        float eps) {
+  __shared__ float part[2][LN_GROUPS][LN_COLS];
+  const int p = threadIdx.x % LN_COLS, grp = threadIdx.x / LN_COLS;
+  const long long n = blockIdx.x * (long long)LN_COLS + p;
   const bool ok = n < N;
   const float mean = ok ? mu[n] : 0.f, r = ok ? rs[n] : 0.f;
   float s1 = 0.f, s2 = 0.f;
-  for (int c = w; c < Cc; c += 4) {
-    float d = 0.f, xc = 0.f;
-    if (ok) {
-      d = dy[(long long)c * N + n];
-      xc = x[(long long)c * N + n] - mean;
-    }
-    const float dyg = d * g[c];
-    s1 += dyg;
-    s2 += dyg * xc;
-    // per-channel sums over the block's 64 positions (wave reduction, fixed order)
-    float a = d * xc * r, bsum = d;
+  // every thread walks its channels (also past-the-end positions, with zeros: the per-channel sums need whole half-waves)
+  for (int c0 = grp; c0 < Cc; c0 += LN_UNROLL * LN_GROUPS) {
+    float d[LN_UNROLL], xc[LN_UNROLL];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      a += __shfl_xor(a, off, 64);
-      bsum += __shfl_xor(bsum, off, 64);
+    for (int u = 0; u < LN_UNROLL; ++u) {
+      const int c = c0 + u * LN_GROUPS;
+      const bool in = ok && c < Cc;
+      d[u] = in ? dy[(long long)c * N + n] : 0.f;
+      xc[u] = in ? x[(long long)c * N + n] - mean : 0.f;
     }
-    if (lane == 0) {
-      pg[(long long)blockIdx.x * Cc + c] = a;
-      pb[(long long)blockIdx.x * Cc + c] = bsum;
+#pragma unroll
+    for (int u = 0; u < LN_UNROLL; ++u) {
+      const int c = c0 + u * LN_GROUPS;
+      if (c >= Cc) break;  // (uniform over the 32 lanes of a channel group)
+      const float dyg = d[u] * g[c];
+      s1 += dyg;
+      s2 += dyg * xc[u];
+      // per-channel sums over the block's 32 positions: a half-wave reduction in fixed order
+      float a = d[u] * xc[u] * r, bsum = d[u];
+#pragma unroll
+      for (int off = LN_COLS / 2; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off, 64);
+        bsum += __shfl_xor(bsum, off, 64);
+      }
+      if (p == 0) {
+        pg[(long long)blockIdx.x * Cc + c] = a;
+        pb[(long long)blockIdx.x * Cc + c] = bsum;
+      }
     }
   }
-  part[0][w][lane] = s1;
-  part[1][w][lane] = s2;
+  part[0][grp][p] = s1;
+  part[1][grp][p] = s2;
   __syncthreads();
   if (!ok) return;
-  const float m1 = (part[0][0][lane] + part[0][1][lane] + part[0][2][lane] + part[0][3][lane]) / (float)Cc;
-  const float m2 = (part[1][0][lane] + part[1][1][lane] + part[1][2][lane] + part[1][3][lane]) / (float)Cc;
+  float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+  for (int gI = 0; gI < LN_GROUPS; ++gI) {
+    t1 += part[0][gI][p];
+    t2 += part[1][gI][p];
+  }
+  const float m1 = t1 / (float)Cc, m2 = t2 / (float)Cc;
   const float sigma = 1.f / r - eps;
   const float k2 = sigma > 0.f ? r * r / sigma * m2 : 0.f;
-  for (int c = w; c < Cc; c += 4) {
+  int c = grp;
+  for (; c + (LN_UNROLL - 1) * LN_GROUPS < Cc; c += LN_UNROLL * LN_GROUPS) {
+    float d[LN_UNROLL], xv[LN_UNROLL];
+#pragma unroll
+    for (int u = 0; u < LN_UNROLL; ++u) {
+      const long long o = (long long)(c + u * LN_GROUPS) * N + n;
+      d[u] = dy[o];
+      xv[u] = x[o];
+    }
+#pragma unroll
+    for (int u = 0; u < LN_UNROLL; ++u) {
+      const int cc = c + u * LN_GROUPS;
+      dx[(long long)cc * N + n] = r * (d[u] * g[cc] - m1) - k2 * (xv[u] - mean);
+    }
+  }
+  for (; c < Cc; c += LN_GROUPS) {
     const long long o = (long long)c * N + n;
     dx[o] = r * (dy[o] * g[c] - m1) - k2 * (x[o] - mean);
   }
@@ -230,12 +311,20 @@ extern "C" int advhip_bn_rows_bwd_f32(const float* dy, const float* x, const flo
   return check_launch("bn_rows_bwd");
 }
 
+extern "C" int advhip_chan_stats_f32(const float* x, float* mu, float* rs, int32_t C, int64_t N, float eps, void* stream) {
+  ADVHIP_REQUIRE(x && mu && rs && C > 0 && N > 0, "chan_stats: bad arguments");
+  const long long blocks = (N + LN_COLS - 1) / LN_COLS;
+  ADVHIP_REQUIRE(blocks < (1ll << 31), "chan_stats: too many positions");
+  hipLaunchKernelGGL(chan_stats_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, x, mu, rs, C, (long long)N, eps);
+  return check_launch("chan_stats");
+}
+
 extern "C" int advhip_chan_layernorm_fwd_f32(const float* x, const float* g, const float* b, float* y, float* mu, float* rs,
                                              int32_t C, int64_t N, float eps, void* stream) {
   ADVHIP_REQUIRE(x && g && b && y && mu && rs && C > 0 && N > 0, "chan_layernorm_fwd: bad arguments");
   const long long blocks = (N + LN_COLS - 1) / LN_COLS;
   ADVHIP_REQUIRE(blocks < (1ll << 31), "chan_layernorm_fwd: too many positions");
-  hipLaunchKernelGGL(chan_layernorm_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, g, b, y, mu, rs, C,
+  hipLaunchKernelGGL(chan_layernorm_fwd_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, x, g, b, y, mu, rs, C,
                      (long long)N, eps);
   return check_launch("chan_layernorm_fwd");
 }
@@ -248,7 +337,7 @@ extern "C" int advhip_chan_layernorm_bwd_f32(const float* dy, const float* x, co
   ADVHIP_REQUIRE(dy && x && g && mu && rs && dx && dg_partial && db_partial && C > 0 && N > 0, "chan_layernorm_bwd: bad arguments");
   const long long blocks = (N + LN_COLS - 1) / LN_COLS;
   ADVHIP_REQUIRE(blocks < (1ll << 31), "chan_layernorm_bwd: too many positions");
-  hipLaunchKernelGGL(chan_layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, x, g, mu, rs, dx,
+  hipLaunchKernelGGL(chan_layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, dy, x, g, mu, rs, dx,
                      dg_partial, db_partial, C, (long long)N, eps);
   return check_launch("chan_layernorm_bwd");
 }
