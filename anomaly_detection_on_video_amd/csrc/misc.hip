@@ -85,16 +85,17 @@ __global__ void normalize_permute_u8_kernel(const uint8_t* __restrict__ x, float
 // bottom-left, bottom-right, centre (torchvision five_crop order; centre offsets are Python-rounded halves, computed by the
 // caller); crops 5..9 = the same five windows of the horizontally flipped frame: pixel (y, x) = frame[top + y][W - 1 - (left + x)].
 // Frame t of clip c = frames[c * fpc + t % len_c], len_c = min(fpc, F - c * fpc) (LoopPad: a short last clip repeats itself).
-struct CropTable { int top[5], left[5]; };
-
+// One wave per output row (clip, crop, c, t, y): the row decode (five divisions) happens once per 224 outputs, the lanes run
+// along x with 16-byte stores (the first form decoded every float4 separately and indexed a by-value crop table: 165 us for
+// 40 crop-clips, VALU-bound at 2.3 TB/s).
 template <int VW>
-__global__ void tencrop_normalize_u8_kernel(const uint8_t* __restrict__ x, float* __restrict__ y, int F, int H, int W, int C,
-                                            int fpc, int cs, CropTable ct, float mean, float stdv, long long total) {
-  // one thread = VW consecutive output columns of one row (VW = 4: one 16-byte store; cs % 4 == 0)
+__global__ __launch_bounds__(256) void tencrop_normalize_u8_kernel(const uint8_t* __restrict__ x, float* __restrict__ y, int F, int H, int W,
+                                                                   int C, int fpc, int cs, int ctop, int cleft, float mean, float stdv,
+                                                                   long long rows) {
+  const int lane = threadIdx.x & 63;
   const int csv = cs / VW;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int xo = (int)(i % csv) * VW;  // output order: (clip, crop, c, t, y, x)
-    long long r = i / csv;
+  for (long long r0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r0 < rows; r0 += (long long)gridDim.x * 4) {
+    long long r = r0;  // output order: (clip, crop, c, t, y, x)
     const int yo = (int)(r % cs);
     r /= cs;
     const int t = (int)(r % fpc);
@@ -106,16 +107,20 @@ __global__ void tencrop_normalize_u8_kernel(const uint8_t* __restrict__ x, float
     const int len = min(fpc, F - clip * fpc);
     const int f = clip * fpc + t % len;
     const int j = crop % 5;
-    const int sy = ct.top[j] + yo;
-    const uint8_t* row = x + (((long long)f * H + sy) * W) * C + c;
-    float v[VW];
+    const int top = j == 4 ? ctop : ((j >> 1) ? H - cs : 0), left = j == 4 ? cleft : ((j & 1) ? W - cs : 0);
+    const uint8_t* row = x + (((long long)f * H + top + yo) * W) * C + c;
+    float* out = y + r0 * cs;
+    for (int q = lane; q < csv; q += 64) {
+      float v[VW];
 #pragma unroll
-    for (int e = 0; e < VW; ++e) {
-      const int sx = crop < 5 ? ct.left[j] + xo + e : W - 1 - (ct.left[j] + xo + e);
-      v[e] = ((float)row[(long long)sx * C] - mean) / stdv;
+      for (int e = 0; e < VW; ++e) {
+        const int xo = q * VW + e;
+        const int sx = crop < 5 ? left + xo : W - 1 - (left + xo);
+        v[e] = ((float)row[(long long)sx * C] - mean) / stdv;
+      }
+      if constexpr (VW == 4) reinterpret_cast<float4*>(out)[q] = make_float4(v[0], v[1], v[2], v[3]);
+      else out[q] = v[0];
     }
-    if constexpr (VW == 4) reinterpret_cast<float4*>(y)[i] = make_float4(v[0], v[1], v[2], v[3]);
-    else y[i] = v[0];
   }
 }
 
@@ -130,18 +135,15 @@ extern "C" int advhip_tencrop_normalize_u8(const uint8_t* frames, float* y, int3
   ADVHIP_REQUIRE(stdv != 0.f, "tencrop_normalize_u8: std must be non-zero");
   // torchvision center_crop: int(round((H - crop) / 2.0)) with Python's round-half-to-even
   auto half_even = [](int d) { return (d % 2 == 0) ? d / 2 : ((d / 2) % 2 == 0 ? d / 2 : d / 2 + 1); };
-  CropTable ct;
-  const int tops[5] = {0, 0, H - crop, H - crop, half_even(H - crop)};
-  const int lefts[5] = {0, W - crop, 0, W - crop, half_even(W - crop)};
-  for (int j = 0; j < 5; ++j) { ct.top[j] = tops[j]; ct.left[j] = lefts[j]; }
+  const int ctop = half_even(H - crop), cleft = half_even(W - crop);
   const long long n_clips = (F + frames_per_clip - 1) / frames_per_clip;
   const bool vec = crop % 4 == 0 && ((uintptr_t)y & 15) == 0;
-  const long long total = n_clips * 10 * C * frames_per_clip * (long long)crop * crop / (vec ? 4 : 1);
-  const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 64);
+  const long long rows = n_clips * 10 * C * frames_per_clip * (long long)crop;
+  const int grid = (int)std::min<long long>((rows + 3) / 4, 256 * 256);
   if (vec) hipLaunchKernelGGL(tencrop_normalize_u8_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, y, F, H, W, C,
-                              frames_per_clip, crop, ct, mean, stdv, total);
+                              frames_per_clip, crop, ctop, cleft, mean, stdv, rows);
   else hipLaunchKernelGGL(tencrop_normalize_u8_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, y, F, H, W, C,
-                          frames_per_clip, crop, ct, mean, stdv, total);
+                          frames_per_clip, crop, ctop, cleft, mean, stdv, rows);
   return check_launch("tencrop_normalize_u8");
 }
 
