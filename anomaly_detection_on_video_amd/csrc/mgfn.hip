@@ -233,6 +233,24 @@ __global__ __launch_bounds__(256) void dwconv_t_bwd_kernel(const float* __restri
   if (threadIdx.x <= K) partial[(long long)blockIdx.x * (K + 1) + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// The rows a k = 3, padding 1 temporal conv contracts with, for its weight gradient dW = dY . U^T:
+//   U[(c * 3 + j), r, t] = x[c, r, t + j - 1]  (0 outside [0, T)), x (C, rows, T) -> U (3 C, rows, T), tap-minor like the weights.
+// One thread per float4 of x's row: reads it (+ one neighbour on each side) and writes the three shifted copies.
+__global__ __launch_bounds__(256) void unfold3_kernel(const float* __restrict__ x, float* __restrict__ u, int T, long long per_c,
+                                                      long long total4) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+    const long long e = i * 4;               // first element of this float4 (T % 4 == 0: a float4 never straddles a row)
+    const long long c = e / per_c, w = e - c * per_c;
+    const int t = (int)(w % T);
+    const float4 v = *reinterpret_cast<const float4*>(x + e);
+    const float l = t > 0 ? x[e - 1] : 0.f, r = t + 4 < T ? x[e + 4] : 0.f;
+    float* o = u + (c * 3) * per_c + w;
+    *reinterpret_cast<float4*>(o) = make_float4(l, v.x, v.y, v.z);                 // tap 0: x[t - 1]
+    *reinterpret_cast<float4*>(o + per_c) = v;                                     // tap 1
+    *reinterpret_cast<float4*>(o + 2 * per_c) = make_float4(v.y, v.z, v.w, r);     // tap 2: x[t + 1]
+  }
+}
+
 // ---- BatchNorm1d over the rows of a (C, N) activation (FocusAttention.norm, modeling_mgfn.py:162, 174) -------------------
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -340,6 +358,15 @@ extern "C" int advhip_chan_layernorm_bwd_f32(const float* dy, const float* x, co
   hipLaunchKernelGGL(chan_layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, dy, x, g, mu, rs, dx,
                      dg_partial, db_partial, C, (long long)N, eps);
   return check_launch("chan_layernorm_bwd");
+}
+
+extern "C" int advhip_unfold3_f32(const float* x, float* u, int32_t C, int64_t rows, int32_t T, void* stream) {
+  ADVHIP_REQUIRE(x && u && C > 0 && rows > 0 && T > 0, "unfold3: bad arguments");
+  ADVHIP_REQUIRE(T % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)u & 15) == 0, "unfold3: T=%d must be a multiple of 4 and the tensors 16-byte aligned", T);
+  const long long per_c = (long long)rows * T, total4 = (long long)C * per_c / 4;
+  const int grid = (int)std::min<long long>((total4 + 255) / 256, 256 * 64);
+  hipLaunchKernelGGL(unfold3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, u, T, per_c, total4);
+  return check_launch("unfold3");
 }
 
 extern "C" int advhip_dwconv_t_fwd_f32(const float* v, const float* w, const float* bias, float* out, int32_t C, int32_t H,

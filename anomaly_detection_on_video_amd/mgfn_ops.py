@@ -147,6 +147,10 @@ def chan_stats(x: torch.Tensor, eps: float) -> Tuple[torch.Tensor, torch.Tensor]
 def _unfold3(x: torch.Tensor) -> torch.Tensor:
     """(C, B, T) -> ((c, tap) = 3C, B*T): the rows a k = 3, padding 1 conv contracts with, tap-minor like the weights."""
     c, b, t = x.shape
+    if x.is_cuda and t % 4 == 0 and x.is_contiguous() and x.dtype == torch.float32:  # one HIP pass (pad + stack: three)
+        u = torch.empty((3 * c, b * t), device=x.device, dtype=torch.float32)
+        check(_lib.load().advhip_unfold3_f32(ptr(x), ptr(u), c, b, t, stream()), "unfold3")
+        return u
     xp = torch.nn.functional.pad(x, (1, 1))
     return torch.stack([xp[:, :, j : j + t] for j in range(3)], dim=1).reshape(3 * c, b * t)
 
@@ -161,6 +165,9 @@ class _LinearCN(torch.autograd.Function):
                     residual=residual.detach().contiguous() if residual is not None else None)
         ctx.save_for_backward(x, weight)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        # y = conv(x) + x (the blocks' `x = scc(x) + x`): dL/dx = conv^T(dy) + dy comes out of ONE launch (dy as the dX GEMM's
+        # residual) instead of a GEMM, a pass-through and autograd's add over the whole activation
+        ctx.res_is_x = residual is not None and residual.data_ptr() == x.data_ptr() and residual.shape == x.shape and cin == cout
         return y
 
     @staticmethod
@@ -169,11 +176,12 @@ class _LinearCN(torch.autograd.Function):
         cout, cin, k = weight.shape
         dy = dy.contiguous()
         dx = dw = db = None
+        fold = ctx.res_is_x and ctx.needs_input_grad[0] and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[0]:
             if k == 1:  # dX = W^T dY: the parameter's own (o, c) layout IS the kernels' [K = o][Cout = c] operand
-                dx = conv_cn(dy, weight.detach().view(cout, cin), cin, 1)
+                dx = conv_cn(dy, weight.detach().view(cout, cin), cin, 1, residual=dy if fold else None)
             else:       # transposed conv: W'[c][o][j] = W[o][c][k-1-j]
-                dx = conv_cn(dy, pack_kc(weight.detach().flip(2).transpose(0, 1)), cin, k)
+                dx = conv_cn(dy, pack_kc(weight.detach().flip(2).transpose(0, 1)), cin, k, residual=dy if fold else None)
         if ctx.needs_input_grad[1]:
             dy2 = dy.view(cout, -1)
             if k == 1:
@@ -182,7 +190,7 @@ class _LinearCN(torch.autograd.Function):
                 dw = ops.gemm_nt(dy2, _unfold3(x.detach())).view(cout, cin, 3)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=(1, 2))
-        return dx, dw, db, (dy if ctx.has_res and ctx.needs_input_grad[3] else None)
+        return dx, dw, db, (None if fold else (dy if ctx.has_res and ctx.needs_input_grad[3] else None))
 
 
 class _FFNCN(torch.autograd.Function):

@@ -291,6 +291,11 @@ int advhip_bn_rows_fwd_f32(const float* x, const float* gamma, const float* beta
 int advhip_bn_rows_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* var, float* dx,
                            float* dgamma, float* dbeta, int32_t C, int64_t N, float eps, void* stream);
 
+/* The operand of a k = 3, padding 1 Conv1d's weight gradient (autograd of nn.Conv1d, modeling_mgfn.py:101,155):
+ * u[(c*3 + j), r, t] = x[c, r, t + j - 1] (zero outside [0, T)), x (C, rows, T) -> u (3C, rows, T); dW = dY . u^T by
+ * advhip_gemm_nt_f32.  T a multiple of 4. */
+int advhip_unfold3_f32(const float* x, float* u, int32_t C, int64_t rows, int32_t T, void* stream);
+
 /* FocusAttention.rel_pos (modeling_mgfn.py:169-171, 176-178): depth-wise temporal conv, one K-tap filter per head, on a
  * (C, rows, T) activation whose channel c belongs to head c % H: out[c,r,t] = bias[h] + sum_j w[h][j] * v[c,r,t+j-K/2]
  * (zero padding).  K in {3, 5}. */

@@ -359,3 +359,16 @@ def test_bn_rows_train_fwd_bwd_vs_torch_batchnorm1d(shape):
     assert rel_err(mean.cpu(), x.double().mean(dim=(1, 2))) < 1e-5 and rel_err(var.cpu(), x.double().var(dim=(1, 2), unbiased=False)) < 1e-5
     assert rel_err(xg.grad.cpu(), xd.grad) < 1e-4
     assert rel_err(gg.grad.cpu(), gd.grad) < 1e-4 and rel_err(bg.grad.cpu(), bd.grad) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(1024, 20, 32), (128, 3, 8), (5, 1, 4), (64, 7, 12)])
+def test_unfold3_is_bit_exact(shape):
+    """advhip_unfold3_f32 (the operand of a k = 3 conv's weight gradient) vs pad + stack of shifted views."""
+    from anomaly_detection_on_video_amd import mgfn_ops
+
+    x = synth_tensor(f"unf{shape}", shape, scale=1.0)
+    c, b, t = shape
+    xp = torch.nn.functional.pad(x, (1, 1))
+    ref = torch.stack([xp[:, :, j : j + t] for j in range(3)], dim=1).reshape(3 * c, b * t)
+    got = mgfn_ops._unfold3(x.to(DEV))
+    assert got.shape == ref.shape and torch.equal(got.cpu(), ref)
