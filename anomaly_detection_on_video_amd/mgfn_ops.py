@@ -82,14 +82,30 @@ def _const(n: int, value: float, dev) -> torch.Tensor:
 
 
 _PACKED: Dict[int, Tuple] = {}
+_EPOCH = 0  # part of every cache stamp below
 
 
-def pack_kc_cached(param: torch.Tensor) -> torch.Tensor:
-    """pack_kc of a parameter, re-done only when the parameter has changed (its version counter moves with every
-    optimizer step; inference re-uses the packed copy call after call)."""
+def invalidate_caches() -> None:
+    """Forget every cached operand derived from parameters (packed weights, folded LayerNorm operands).  The model calls
+    this at the start of every forward that will be differentiated and the runner after every optimizer step: version
+    counters alone miss torch's fused optimizers and `.data` updates, and a layer may take the torch path in training but
+    the HIP path (and its cache) at inference.  Call it yourself after changing parameters in any other such way."""
+    global _EPOCH
+    _EPOCH += 1
+
+
+
+def pack_kc_cached(param: torch.Tensor, fresh: bool = False) -> torch.Tensor:
+    """pack_kc of a parameter; inference re-uses the packed copy call after call while (data_ptr, version) stay put.
+    `fresh` (a forward that will be differentiated: the weights are about to change): always re-pack and DROP the cached
+    copy -- version counters cannot be relied on there (torch's fused optimizers update parameters without moving them),
+    so a later no-grad forward packs again instead of finding a stale copy."""
     key = id(param)
+    if fresh:
+        _PACKED.pop(key, None)
+        return pack_kc(param.detach())
     hit = _PACKED.get(key)
-    stamp = (param.data_ptr(), param._version, tuple(param.shape))
+    stamp = (param.data_ptr(), param._version, tuple(param.shape), _EPOCH)
     if hit is None or hit[0]() is not param or hit[1] != stamp:  # (ids are re-used once a tensor is gone: check it is the same object)
         if len(_PACKED) > 1024:
             for k in [k for k, v in _PACKED.items() if v[0]() is None]:  # parameters of discarded models
@@ -159,9 +175,9 @@ class _LinearCN(torch.autograd.Function):
     """y = conv1d_k(x; W) + b (+ residual), k in {1, 3}, no activation."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual):
+    def forward(ctx, x, weight, bias, residual, fresh):
         cout, cin, k = weight.shape
-        y = conv_cn(x, pack_kc_cached(weight), cout, k, shift=bias.detach() if bias is not None else None,
+        y = conv_cn(x, pack_kc_cached(weight, fresh), cout, k, shift=bias.detach() if bias is not None else None,
                     residual=residual.detach().contiguous() if residual is not None else None)
         ctx.save_for_backward(x, weight)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
@@ -190,7 +206,7 @@ class _LinearCN(torch.autograd.Function):
                 dw = ops.gemm_nt(dy2, _unfold3(x.detach())).view(cout, cin, 3)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=(1, 2))
-        return dx, dw, db, (None if fold else (dy if ctx.has_res and ctx.needs_input_grad[3] else None))
+        return dx, dw, db, (None if fold else (dy if ctx.has_res and ctx.needs_input_grad[3] else None)), None
 
 
 class _FFNCN(torch.autograd.Function):
@@ -199,12 +215,12 @@ class _FFNCN(torch.autograd.Function):
     two + two backward (GELU' in the epilogue of the GEMM that produces dL/dh)."""
 
     @staticmethod
-    def forward(ctx, xh, x_res, w1, b1, w2, b2):
+    def forward(ctx, xh, x_res, w1, b1, w2, b2, fresh):
         hid, dim = w1.shape[0], w1.shape[1]
         need_z = any(ctx.needs_input_grad)
-        out = conv_cn(xh, pack_kc_cached(w1), hid, 1, shift=b1.detach(), act=ACT_GELU, want_preact=need_z)
+        out = conv_cn(xh, pack_kc_cached(w1, fresh), hid, 1, shift=b1.detach(), act=ACT_GELU, want_preact=need_z)
         h, z = out if need_z else (out, None)
-        y = conv_cn(h, pack_kc_cached(w2), dim, 1, shift=b2.detach(), residual=x_res.detach().contiguous())
+        y = conv_cn(h, pack_kc_cached(w2, fresh), dim, 1, shift=b2.detach(), residual=x_res.detach().contiguous())
         if need_z:
             ctx.save_for_backward(xh, z, h, w1, w2)
         return y
@@ -220,15 +236,23 @@ class _FFNCN(torch.autograd.Function):
         dw1 = ops.gemm_nt(dz.view(hid, -1), xh.detach().view(dim, -1)).view(hid, dim, 1) if ctx.needs_input_grad[2] else None
         db2 = dy.sum(dim=(1, 2)) if ctx.needs_input_grad[5] else None
         db1 = dz.sum(dim=(1, 2)) if ctx.needs_input_grad[3] else None
-        return dxh, (dy if ctx.needs_input_grad[1] else None), dw1, db1, dw2, db2
+        return dxh, (dy if ctx.needs_input_grad[1] else None), dw1, db1, dw2, db2, None
+
+
+def _will_train(*params) -> bool:
+    """This forward is being recorded for a backward pass that can reach these parameters."""
+    return torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params)
 
 
 def linear_cn(x: torch.Tensor, conv: torch.nn.Conv1d, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    return _LinearCN.apply(x.contiguous(), conv.weight, conv.bias, residual)
+    return _LinearCN.apply(x.contiguous(), conv.weight, conv.bias, residual, _will_train(conv.weight, conv.bias))
 
 
 def ffn_cn(xh: torch.Tensor, x_res: torch.Tensor, in_conv: torch.nn.Conv1d, out_conv: torch.nn.Conv1d) -> torch.Tensor:
-    return _FFNCN.apply(xh.contiguous(), x_res, in_conv.weight, in_conv.bias, out_conv.weight, out_conv.bias)
+    fresh = _will_train(in_conv.weight, in_conv.bias, out_conv.weight, out_conv.bias)
+    if fresh:
+        _FOLDED.pop(id(in_conv), None)  # (the folded-LayerNorm operands of the inference form: same reasoning as pack_kc_cached)
+    return _FFNCN.apply(xh.contiguous(), x_res, in_conv.weight, in_conv.bias, out_conv.weight, out_conv.bias, fresh)
 
 
 _FOLDED: Dict[int, Tuple] = {}
@@ -242,7 +266,7 @@ def ffn_cn_folded_ln(x: torch.Tensor, norm, in_conv: torch.nn.Conv1d, out_conv: 
     x = x.contiguous()
     hid, dim = in_conv.weight.shape[0], in_conv.weight.shape[1]
     params = (in_conv.weight, in_conv.bias, norm.g, norm.b)
-    stamp = tuple((p.data_ptr(), p._version) for p in params)
+    stamp = tuple((p.data_ptr(), p._version) for p in params) + (_EPOCH,)
     hit = _FOLDED.get(id(in_conv))
     if hit is None or hit[0]() is not in_conv or hit[1] != stamp:
         if len(_FOLDED) > 256:

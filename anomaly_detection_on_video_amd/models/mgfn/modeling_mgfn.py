@@ -325,6 +325,8 @@ class MGFNModel(MGFNPreTrainedModel):
         self.layers = nn.Sequential(*stages)
 
     def forward(self, x: torch.Tensor) -> MGFNModelOutput:
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            mgfn_ops.invalidate_caches()  # the weights are about to be updated: no cached packed copy may outlive this pass
         # internal layout (C, B, T); `outputs` is returned in the reference's (B, C, T) shape (a view)
         return MGFNModelOutput(outputs=self.layers(self.amplifier(x)).permute(1, 0, 2))
 

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 from torch.utils.data import DataLoader
 
-from . import metrics
+from . import metrics, mgfn_ops
 from .dataset import build_feature_dataset
 
 
@@ -60,7 +60,11 @@ class VideoAnomalyDetectionRunner:
     # runner.py:53-59 -- Adam with L2-in-gradient weight decay, no scheduler
     def configure_optimizers(self) -> List[torch.optim.Optimizer]:
         opt = self.hparams.optimizer
-        return [torch.optim.Adam(self.model.parameters(), lr=float(opt["learning_rate"]), weight_decay=float(opt["weight_decay"]))]
+        params = list(self.model.parameters())
+        # same update rule as the reference's torch.optim.Adam; on GPU parameters torch's fused implementation (a few launches
+        # instead of ~25 multi-tensor ones: 0.73 -> 0.3 ms of the 19-ms step)
+        fused = bool(params) and all(p.is_cuda for p in params)
+        return [torch.optim.Adam(params, lr=float(opt["learning_rate"]), weight_decay=float(opt["weight_decay"]), fused=fused)]
 
     # runner.py:62-90 (metrics; the matplotlib/wandb chart is out of scope)
     def on_validation_epoch_end(self) -> Dict[str, float]:
@@ -255,6 +259,7 @@ class Trainer:
                 if self.gradient_clip_val:
                     torch.nn.utils.clip_grad_norm_(runner.model.parameters(), self.gradient_clip_val)
                 optimizer.step()
+                mgfn_ops.invalidate_caches()  # (fused optimizers do not move version counters)
                 self.global_step += 1
                 if self.global_step % self.log_every_n_steps == 0:
                     m = {"train_loss": runner.logged["train_loss"], "epoch": epoch}

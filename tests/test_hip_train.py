@@ -16,6 +16,47 @@ DEV = "cuda:0"
 TOL = 1e-3
 
 
+def test_eval_after_fused_optimizer_steps_sees_the_new_weights(monkeypatch):
+    """torch's fused Adam updates parameters WITHOUT moving their version counters: the packed / folded weight copies the
+    inference path caches must not survive a training step.  eval -> 2 fused steps (an eval in between) -> eval: the logits
+    of the HIP path must equal those of the plain-torch path on the SAME updated parameters (a stale packed copy would
+    reproduce the logits from before the step)."""
+    from anomaly_detection_on_video_amd import mgfn_ops
+    from anomaly_detection_on_video_amd.models.mgfn import MGFNConfig, MGFNForVideoAnomalyDetection
+
+    model = MGFNForVideoAnomalyDetection(MGFNConfig())
+    model.load_state_dict(synth_module_state_dict(model))
+    model = model.to(DEV)
+    video = mgfn_inputs(4, 32, 3).to(DEV)
+    nl, al = torch.zeros(2, device=DEV), torch.ones(2, device=DEV)
+    grabbed = []
+    model.fc.register_forward_hook(lambda m, i, o: grabbed.append(o.detach().cpu()))  # logits (the scores saturate)
+
+    def logits(torch_path=False):
+        model.eval()
+        grabbed.clear()
+        with torch.no_grad(), monkeypatch.context() as mp:
+            if torch_path:
+                mp.setattr(mgfn_ops, "eligible", lambda *a: False)
+                mp.setattr(mgfn_ops, "fused_ok", lambda x: False)
+            model(video=video)
+        return grabbed[-1]
+
+    before = logits()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4, fused=True)
+    versions = [p._version for p in model.parameters()]
+    for step in range(2):
+        model.train()
+        opt.zero_grad()
+        model(video=mgfn_inputs(4, 32, 20 + step).to(DEV), abnormal_labels=al, normal_labels=nl).loss.backward()
+        opt.step()
+        logits()  # an eval between the steps re-creates the cached copies: the next step must drop them again
+    assert versions == [p._version for p in model.parameters()], "fused Adam moved the version counters after all"
+    after, ref = logits(), logits(torch_path=True)
+    assert rel_err(after, before) > 1e-2, "two optimizer steps changed nothing"
+    assert rel_err(after, ref) < 1e-4, rel_err(after, ref)
+
+
 def test_adam_training_steps_track_the_cpu_oracle():
     """3 Adam steps (lr 1e-3, weight decay 5e-4: runner.py:53-59) in train mode (BatchNorm1d batch
     statistics) with the top-k keep-mask pinned to ones: loss curve and weights vs the oracle."""

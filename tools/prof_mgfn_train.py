@@ -16,7 +16,7 @@ m.load_state_dict(synth_module_state_dict(m))
 m = m.to(dev).train()
 vb = torch.rand(32, 10, 32, 2049, device=dev)
 al, nl = torch.ones(16, device=dev), torch.zeros(16, device=dev)
-opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-4)
+opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-4, fused=os.environ.get('ADV_ADAM_FUSED', '1') == '1')
 
 
 def step():
