@@ -2400,15 +2400,16 @@ extern "C" int advhip_conv3d_bn_relu_maxpool233_f32(const advhip_conv3d_desc* d,
   a.y_bstride = 0; a.Tp = Tp; a.relu = 1;
   const int nbh = (2 * Hp + 1 + 3) / 4, nbw = (2 * Wp + 1 + 15) / 16;
   set_bricks(a, Tp, nbh, nbw);
+  // (every check before the first launch: a rejected call must not leave half an op enqueued)
+  ADVHIP_REQUIRE(nbw <= MERGE_MAX_NBW, "conv3d+pool233: pooled width %d above %d", Wp, MERGE_MAX_NBW * 8 - 1);
+  const long long rows = (long long)d->B * a.tiles_n * 2 * Tp * Hp;
+  ADVHIP_REQUIRE(rows < (1ll << 31), "conv3d+pool233: too many output rows");
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
   const bool nocheck = d->kt == 1 && d->kh == 1 && d->kw == 1 && d->pt == 0 && d->ph == 0 && d->pw == 0 && g.K == g.Kpad;
   if (nocheck) hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, false, 2, EPI_POOL233>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, true, 2, EPI_POOL233>), grid, dim3(256), 0, st, a);
   if (int rc = check_launch("conv3d+pool233")) return rc;
-  ADVHIP_REQUIRE(nbw <= MERGE_MAX_NBW, "conv3d+pool233: pooled width %d above %d", Wp, MERGE_MAX_NBW * 8 - 1);
-  const long long rows = (long long)d->B * a.tiles_n * 2 * Tp * Hp;
-  ADVHIP_REQUIRE(rows < (1ll << 31), "conv3d+pool233: too many output rows");
   const unsigned gx = (unsigned)std::min<long long>(rows, 1 << 20), gy = (unsigned)((rows + gx - 1) / gx);
   hipLaunchKernelGGL(stem_pool_merge_kernel, dim3(gx, gy), dim3(256), (size_t)2 * nbw * 288 * sizeof(float), st, reinterpret_cast<const float*>(workspace), y, d->Cout, Tp,
                      Hp, Wp, nbh, nbw, a.tiles_n, FastDiv::make((unsigned)Wp), rows, ybs);
@@ -2489,12 +2490,13 @@ extern "C" int advhip_conv3d_u8_tencrop_bn_relu_maxpool233_f32(const advhip_conv
   a.y_bstride = 0; a.Tp = Tp; a.relu = 1;
   const int nbh = (2 * Hp + 1 + 3) / 4, nbw = (2 * Wp + 1 + 15) / 16;
   set_bricks(a, Tp, nbh, nbw);
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, true, 2, EPI_POOL233, true>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, st, a);
-  if (int rc = check_launch("conv3d u8+pool233")) return rc;
+  // (every check before the first launch: a rejected call must not leave half an op enqueued)
   ADVHIP_REQUIRE(nbw <= MERGE_MAX_NBW, "conv3d u8+pool233: pooled width %d above %d", Wp, MERGE_MAX_NBW * 8 - 1);
   const long long rows = (long long)d->B * a.tiles_n * 2 * Tp * Hp;
   ADVHIP_REQUIRE(rows < (1ll << 31), "conv3d u8+pool233: too many output rows");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, true, 2, EPI_POOL233, true>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, st, a);
+  if (int rc = check_launch("conv3d u8+pool233")) return rc;
   const unsigned gx = (unsigned)std::min<long long>(rows, 1 << 20), gy = (unsigned)((rows + gx - 1) / gx);
   hipLaunchKernelGGL(stem_pool_merge_kernel, dim3(gx, gy), dim3(256), (size_t)2 * nbw * 288 * sizeof(float), st, reinterpret_cast<const float*>(workspace), y, d->Cout, Tp,
                      Hp, Wp, nbh, nbw, a.tiles_n, FastDiv::make((unsigned)Wp), rows, ybs);
@@ -2582,12 +2584,13 @@ extern "C" int advhip_conv3d_u8_taps_tencrop_bn_relu_maxpool233_f32(const advhip
   a.y_bstride = 0; a.Tp = Tp; a.relu = 1;
   const int nbh = (2 * Hp + 1 + 3) / 4, nbw = (2 * Wp + 1 + 15) / 16;
   set_bricks(a, Tp, nbh, nbw);
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL((stem_u8_tap_kernel<U8_TAPS_PER_TILE>), dim3((unsigned)a.tiles_m), dim3(256), 0, st, a);
-  if (int rc = check_launch("conv3d u8 taps+pool233")) return rc;
+  // (every check before the first launch: a rejected call must not leave half an op enqueued)
   ADVHIP_REQUIRE(nbw <= MERGE_MAX_NBW, "conv3d u8 taps+pool233: pooled width %d above %d", Wp, MERGE_MAX_NBW * 8 - 1);
   const long long rows = (long long)d->B * a.tiles_n * 2 * Tp * Hp;
   ADVHIP_REQUIRE(rows < (1ll << 31), "conv3d u8 taps+pool233: too many output rows");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((stem_u8_tap_kernel<U8_TAPS_PER_TILE>), dim3((unsigned)a.tiles_m), dim3(256), 0, st, a);
+  if (int rc = check_launch("conv3d u8 taps+pool233")) return rc;
   const unsigned gx = (unsigned)std::min<long long>(rows, 1 << 20), gy = (unsigned)((rows + gx - 1) / gx);
   hipLaunchKernelGGL(stem_pool_merge_kernel, dim3(gx, gy), dim3(256), (size_t)2 * nbw * 288 * sizeof(float), st, reinterpret_cast<const float*>(workspace), y, d->Cout, Tp,
                      Hp, Wp, nbh, nbw, a.tiles_n, FastDiv::make((unsigned)Wp), rows, ybs);

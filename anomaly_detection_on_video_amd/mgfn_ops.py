@@ -40,9 +40,21 @@ MIN_CHANNELS_INFER = int(os.environ.get("ADV_MGFN_HIP_MIN_CHANNELS", "64"))
 MIN_CHANNELS_TRAIN = 128
 
 
+def _on_current_device(x: torch.Tensor) -> bool:
+    """The kernels launch on the CURRENT device's stream: a tensor on another GPU takes the torch ops instead."""
+    return x.is_cuda and x.device.index == torch.cuda.current_device()
+
+
 def eligible(cin: int, cout: int, x: torch.Tensor) -> bool:
-    floor = MIN_CHANNELS_TRAIN if torch.is_grad_enabled() else MIN_CHANNELS_INFER
-    return x.is_cuda and x.dtype == torch.float32 and min(cin, cout) >= floor and cout % 64 == 0 and cin % 32 == 0
+    grad = torch.is_grad_enabled()
+    floor = MIN_CHANNELS_TRAIN if grad else MIN_CHANNELS_INFER
+    if not (_on_current_device(x) and x.dtype == torch.float32 and min(cin, cout) >= floor and cout % 64 == 0 and cin % 32 == 0):
+        return False
+    if grad:  # the backward GEMMs have their own shape rules: dX = W^T dY is a conv with Cout = cin (a multiple of 64), dW = dY X^T
+        #       contracts over the B*T positions in 16-wide k-tiles of 16-byte aligned rows
+        npos = x.numel() // max(x.shape[0], 1)
+        return cin % 64 == 0 and npos % 16 == 0
+    return True
 
 
 ALGO_SMALL = _lib.ALGO_DMA2_BASE + _lib.ALGO_IGEMM_64x64  # few output tiles: 64 x 64 tiles (+ split-K inside the launch)
@@ -69,7 +81,7 @@ def _ktab(d: ConvDesc, dev) -> torch.Tensor:
         lib = _lib.load()
         rows = lib.advhip_conv3d_packed_rows(C.byref(d))
         tab = torch.empty((rows * 6,), device=dev, dtype=torch.int32)
-        check(lib.advhip_conv3d_build_ktab(C.byref(d), ptr(tab), stream()), "build_ktab")
+        check(lib.advhip_conv3d_build_ktab(C.byref(d), ptr(tab), stream(dev)), "build_ktab")
         _KTABS[key] = tab
     return tab
 
@@ -120,17 +132,22 @@ def pack_kc(w: torch.Tensor) -> torch.Tensor:
     d = _desc(cin, cout, k, 1, 1, 0)
     lib = _lib.load()
     wp = torch.empty((lib.advhip_conv3d_packed_rows(C.byref(d)), cout), device=w.device, dtype=torch.float32)
-    check(lib.advhip_conv3d_pack_weight_f32(C.byref(d), ptr(w.contiguous()), ptr(wp), stream()), "pack_weight")
+    _lib.require_gpu(w, contiguous=False)
+    check(lib.advhip_conv3d_pack_weight_f32(C.byref(d), ptr(w.contiguous()), ptr(wp), stream(w)), "pack_weight")
     return wp
 
 
 def conv_cn(x: torch.Tensor, w_packed: torch.Tensor, cout: int, k: int = 1, shift: Optional[torch.Tensor] = None,
             residual: Optional[torch.Tensor] = None, act: int = ACT_NONE, want_preact: bool = False,
             dact_z: Optional[torch.Tensor] = None, ln: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None):
-    """act(conv1d_k(x) + shift) (+ residual) for x (Cin, B, T) contiguous -> (Cout, B, T) [, pre-activation].  One launch."""
+    """act(conv1d_k(x) + shift) or conv1d_k(x) + shift + residual for x (Cin, B, T) contiguous -> (Cout, B, T) [, pre-activation].
+    One launch, on torch's current stream of x's device (which must be the current device)."""
     cin, b, t = x.shape
+    _lib.require_gpu(x, w_packed, shift, residual, dact_z, *(ln or ()), contiguous=False)
     if not x.is_contiguous():
         raise _lib.HipExtensionError("conv_cn needs a contiguous (C, B, T) activation")
+    if act != ACT_NONE and residual is not None:  # (the conv epilogue adds the residual BEFORE the activation, advhip_bgemm_f32 after)
+        raise ValueError("conv_cn: an activation together with a residual is not offered (the two GEMM entry points order them differently)")
     d = _desc(cin, cout, k, 1 if k == 1 else b, b * t if k == 1 else t, act)
     dev = x.device
     y = torch.empty((cout, b, t), device=dev, dtype=torch.float32)
@@ -146,29 +163,103 @@ def conv_cn(x: torch.Tensor, w_packed: torch.Tensor, cout: int, k: int = 1, shif
     ws = ops.workspace(dev, need)
     check(lib.advhip_conv3d_bn_act_ex_f32(C.byref(d), ptr(x), 0, ptr(w_packed), ptr(_ktab(d, dev)), ptr(_const(cout, 1.0, dev)),
                                           ptr(shift if shift is not None else _const(cout, 0.0, dev)), ptr(residual), ptr(y), 0,
-                                          C.byref(ep), ptr(ws), need, stream()), "conv_cn")
+                                          C.byref(ep), ptr(ws), need, stream(x)), "conv_cn")
     return (y, z) if want_preact else y
 
 
 def chan_stats(x: torch.Tensor, eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
     """(mean, 1 / (std_biased + eps)) over the channels of a contiguous (C, B, T) activation, per position."""
+    _lib.require_gpu(x)
     c = x.shape[0]
     n = x.numel() // c
     mu = torch.empty((n,), device=x.device, dtype=torch.float32)
     rs = torch.empty_like(mu)
-    check(_lib.load().advhip_chan_stats_f32(ptr(x), ptr(mu), ptr(rs), c, n, C.c_float(eps), stream()), "chan_stats")
+    check(_lib.load().advhip_chan_stats_f32(ptr(x), ptr(mu), ptr(rs), c, n, C.c_float(eps), stream(x)), "chan_stats")
     return mu, rs
 
 
 def _unfold3(x: torch.Tensor) -> torch.Tensor:
     """(C, B, T) -> ((c, tap) = 3C, B*T): the rows a k = 3, padding 1 conv contracts with, tap-minor like the weights."""
     c, b, t = x.shape
-    if x.is_cuda and t % 4 == 0 and x.is_contiguous() and x.dtype == torch.float32:  # one HIP pass (pad + stack: three)
+    if _on_current_device(x) and t % 4 == 0 and x.is_contiguous() and x.dtype == torch.float32:  # one HIP pass (pad + stack: three)
         u = torch.empty((3 * c, b * t), device=x.device, dtype=torch.float32)
-        check(_lib.load().advhip_unfold3_f32(ptr(x), ptr(u), c, b, t, stream()), "unfold3")
+        check(_lib.load().advhip_unfold3_f32(ptr(x), ptr(u), c, b, t, stream(x)), "unfold3")
         return u
     xp = torch.nn.functional.pad(x, (1, 1))
     return torch.stack([xp[:, :, j : j + t] for j in range(3)], dim=1).reshape(3 * c, b * t)
+
+
+# ---- weight / bias gradients beside the dX chain -------------------------------------------------------------------------
+# Inside `with overlapped_backward():` the backward of the GEMM-shaped layers issues dW = dY X^T and db = rowsum(dY) on a side
+# stream, forked off the stream the dX chain runs on; leaving the context joins it (before the optimizer reads the
+# gradients).  dW is a third of the step's FLOPs and none of it is on the critical path of the backward pass; its tails and
+# the memory-bound reductions then run beside the next layer's dX GEMM.  Works eagerly and under graph capture (the fork /
+# join become graph edges).  Outside the context everything runs on the current stream, as before.
+_SIDE: Dict[int, torch.cuda.Stream] = {}
+_OVERLAP = {"on": False, "used": set()}
+
+
+def ensure_side_stream(dev: Optional[int] = None) -> torch.cuda.Stream:
+    """The side stream of a device (created on first use -- call this BEFORE a graph capture: streams cannot be created inside one)."""
+    dev = torch.cuda.current_device() if dev is None else dev
+    side = _SIDE.get(dev)
+    if side is None:
+        side = _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return side
+
+
+class overlapped_backward:
+    def __init__(self, enabled: bool = True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        self.prev = _OVERLAP["on"]
+        _OVERLAP["on"] = bool(self.enabled) and torch.cuda.is_available()
+        if _OVERLAP["on"]:
+            ensure_side_stream()
+        return self
+
+    def __exit__(self, *exc):
+        _OVERLAP["on"] = self.prev
+        for dev in list(_OVERLAP["used"]):  # join: whatever consumes the gradients next is ordered after the side stream
+            torch.cuda.current_stream(dev).wait_stream(_SIDE[dev])
+        _OVERLAP["used"].clear()
+        return False
+
+
+class _Fork:
+    """`with _Fork(dy, x, ...):` -- the body runs on the side stream after everything issued so far on the current stream;
+    the named tensors (inputs produced on the current stream) are kept alive for it."""
+
+    def __init__(self, *tensors):
+        self.tensors = [t for t in tensors if t is not None]
+        self.ctx = None
+
+    def __enter__(self):
+        if not _OVERLAP["on"] or not self.tensors:
+            return self
+        dev = self.tensors[0].device.index
+        side = ensure_side_stream(dev)
+        self.main = torch.cuda.current_stream(dev)
+        side.wait_stream(self.main)
+        for t in self.tensors:
+            t.record_stream(side)
+        _OVERLAP["used"].add(dev)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def out(self, *tensors):
+        """Results produced on the side stream and consumed (after the join) on the main one."""
+        if self.ctx is not None:
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.main)
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
 
 
 class _LinearCN(torch.autograd.Function):
@@ -198,14 +289,16 @@ class _LinearCN(torch.autograd.Function):
                 dx = conv_cn(dy, weight.detach().view(cout, cin), cin, 1, residual=dy if fold else None)
             else:       # transposed conv: W'[c][o][j] = W[o][c][k-1-j]
                 dx = conv_cn(dy, pack_kc(weight.detach().flip(2).transpose(0, 1)), cin, k, residual=dy if fold else None)
-        if ctx.needs_input_grad[1]:
-            dy2 = dy.view(cout, -1)
-            if k == 1:
-                dw = ops.gemm_nt(dy2, x.detach().view(cin, -1)).view(cout, cin, 1)
-            else:
-                dw = ops.gemm_nt(dy2, _unfold3(x.detach())).view(cout, cin, 3)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum(dim=(1, 2))
+        with _Fork(dy, x) as fk:
+            if ctx.needs_input_grad[1]:
+                dy2 = dy.view(cout, -1)
+                if k == 1:
+                    dw = ops.gemm_nt(dy2, x.detach().view(cin, -1)).view(cout, cin, 1)
+                else:
+                    dw = ops.gemm_nt(dy2, _unfold3(x.detach())).view(cout, cin, 3)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = dy.sum(dim=(1, 2))
+            fk.out(dw, db)
         return dx, dw, db, (None if fold else (dy if ctx.has_res and ctx.needs_input_grad[3] else None)), None
 
 
@@ -230,12 +323,16 @@ class _FFNCN(torch.autograd.Function):
         xh, z, h, w1, w2 = ctx.saved_tensors
         hid, dim = w1.shape[0], w1.shape[1]
         dy = dy.contiguous()
+        with _Fork(dy, h) as fk:
+            dw2 = ops.gemm_nt(dy.view(dim, -1), h.view(hid, -1)).view(dim, hid, 1) if ctx.needs_input_grad[4] else None
+            db2 = dy.sum(dim=(1, 2)) if ctx.needs_input_grad[5] else None
+            fk.out(dw2, db2)
         dz = conv_cn(dy, w2.detach().view(dim, hid), hid, 1, dact_z=z)          # (W2^T dY) * GELU'(z)
+        with _Fork(dz, xh) as fk:
+            dw1 = ops.gemm_nt(dz.view(hid, -1), xh.detach().view(dim, -1)).view(hid, dim, 1) if ctx.needs_input_grad[2] else None
+            db1 = dz.sum(dim=(1, 2)) if ctx.needs_input_grad[3] else None
+            fk.out(dw1, db1)
         dxh = conv_cn(dz, w1.detach().view(hid, dim), dim, 1) if ctx.needs_input_grad[0] else None
-        dw2 = ops.gemm_nt(dy.view(dim, -1), h.view(hid, -1)).view(dim, hid, 1) if ctx.needs_input_grad[4] else None
-        dw1 = ops.gemm_nt(dz.view(hid, -1), xh.detach().view(dim, -1)).view(hid, dim, 1) if ctx.needs_input_grad[2] else None
-        db2 = dy.sum(dim=(1, 2)) if ctx.needs_input_grad[5] else None
-        db1 = dz.sum(dim=(1, 2)) if ctx.needs_input_grad[3] else None
         return dxh, (dy if ctx.needs_input_grad[1] else None), dw1, db1, dw2, db2, None
 
 
@@ -288,13 +385,14 @@ class _ChanLayerNorm(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, g, b, eps):
+        _lib.require_gpu(x, g, b, contiguous=False)
         c = x.shape[0]
         n = x.numel() // c
         y = torch.empty_like(x)
         mu = torch.empty((n,), device=x.device, dtype=torch.float32)
         rs = torch.empty_like(mu)
         gf, bf = g.detach().reshape(c).contiguous(), b.detach().reshape(c).contiguous()
-        check(_lib.load().advhip_chan_layernorm_fwd_f32(ptr(x), ptr(gf), ptr(bf), ptr(y), ptr(mu), ptr(rs), c, n, C.c_float(eps), stream()),
+        check(_lib.load().advhip_chan_layernorm_fwd_f32(ptr(x), ptr(gf), ptr(bf), ptr(y), ptr(mu), ptr(rs), c, n, C.c_float(eps), stream(x)),
               "chan_layernorm_fwd")
         ctx.save_for_backward(x, gf, mu, rs)
         ctx.eps, ctx.gshape = eps, g.shape
@@ -312,7 +410,7 @@ class _ChanLayerNorm(torch.autograd.Function):
         pg = torch.empty((rows, c), device=x.device, dtype=torch.float32)
         pb = torch.empty_like(pg)
         check(lib.advhip_chan_layernorm_bwd_f32(ptr(dy), ptr(x), ptr(gf), ptr(mu), ptr(rs), ptr(dx), ptr(pg), ptr(pb), c, n,
-                                                C.c_float(ctx.eps), stream()), "chan_layernorm_bwd")
+                                                C.c_float(ctx.eps), stream(x)), "chan_layernorm_bwd")
         return dx, pg.sum(0).view(ctx.gshape), pb.sum(0).view(ctx.gshape), None
 
 
@@ -321,11 +419,12 @@ class _DWConvT(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, v, weight, bias):
+        _lib.require_gpu(v, weight, bias, contiguous=False)
         c, b, t = v.shape
         h, _, k = weight.shape
         out = torch.empty_like(v)
         w2 = weight.detach().reshape(h, k).contiguous()
-        check(_lib.load().advhip_dwconv_t_fwd_f32(ptr(v), ptr(w2), ptr(bias.detach().contiguous()), ptr(out), c, h, b, t, k, stream()), "dwconv_t_fwd")
+        check(_lib.load().advhip_dwconv_t_fwd_f32(ptr(v), ptr(w2), ptr(bias.detach().contiguous()), ptr(out), c, h, b, t, k, stream(v)), "dwconv_t_fwd")
         ctx.save_for_backward(v, w2)
         ctx.wshape = weight.shape
         return out
@@ -340,13 +439,13 @@ class _DWConvT(torch.autograd.Function):
         chunks = lib.advhip_dwconv_t_bwd_chunks(c, b)
         dv = torch.empty_like(v)
         partial = torch.empty((c * chunks, k + 1), device=v.device, dtype=torch.float32)
-        check(lib.advhip_dwconv_t_bwd_f32(ptr(dout), ptr(v), ptr(w2), ptr(dv), ptr(partial), c, h, b, t, k, stream()), "dwconv_t_bwd")
+        check(lib.advhip_dwconv_t_bwd_f32(ptr(dout), ptr(v), ptr(w2), ptr(dv), ptr(partial), c, h, b, t, k, stream(v)), "dwconv_t_bwd")
         per_head = partial.view(c // h, h, chunks, k + 1).sum(dim=(0, 2))  # channel = c_idx * H + h_idx
         return dv, per_head[:, :k].reshape(ctx.wshape), per_head[:, k].contiguous()
 
 
 def fused_ok(x: torch.Tensor) -> bool:
-    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 3
+    return _on_current_device(x) and x.dtype == torch.float32 and x.dim() == 3
 
 
 def chan_layernorm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
@@ -363,13 +462,14 @@ class _BNRowsTrain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
+        _lib.require_gpu(x, gamma, beta, contiguous=False)
         c = x.shape[0]
         n = x.numel() // c
         y = torch.empty_like(x)
         mean = torch.empty((c,), device=x.device, dtype=torch.float32)
         var = torch.empty_like(mean)
         check(_lib.load().advhip_bn_rows_fwd_f32(ptr(x), ptr(gamma.detach()), ptr(beta.detach()), ptr(y), ptr(mean), ptr(var), c, n,
-                                                 C.c_float(eps), stream()), "bn_rows_fwd")
+                                                 C.c_float(eps), stream(x)), "bn_rows_fwd")
         ctx.save_for_backward(x, gamma, mean, var)
         ctx.eps = eps
         ctx.mark_non_differentiable(mean, var)
@@ -384,7 +484,7 @@ class _BNRowsTrain(torch.autograd.Function):
         dg = torch.empty((c,), device=x.device, dtype=torch.float32)
         db = torch.empty_like(dg)
         check(_lib.load().advhip_bn_rows_bwd_f32(ptr(dy.contiguous()), ptr(x), ptr(gamma.detach()), ptr(mean), ptr(var), ptr(dx), ptr(dg),
-                                                 ptr(db), c, n, C.c_float(ctx.eps), stream()), "bn_rows_bwd")
+                                                 ptr(db), c, n, C.c_float(ctx.eps), stream(x)), "bn_rows_bwd")
         return dx, dg, db, None
 
 

@@ -153,6 +153,10 @@ class ExtractScoreStream:
                     lane.wait_event(self._scored_done)
 
             self._after_ring_read = ring_read
+            if self._scored_done is not None and len(self._videos_completing()) > 1:
+                # ring_read orders only the LAST video of a step behind the previous scoring; when a step completes several
+                # videos of this rank the earlier ones must wait for it too (lazily built operand caches are shared)
+                lane.wait_event(self._scored_done)
             try:
                 scored = self.ingest(gathered)
             finally:
@@ -173,6 +177,11 @@ class ExtractScoreStream:
             if ev is not None:
                 cur.wait_event(ev)
 
+    def _videos_completing(self) -> List[int]:
+        """Videos of this rank whose last crop-clip arrives with the NEXT global batch."""
+        first_done = self.pos // self.per_video
+        return [v for v in range(first_done, (self.pos + self.global_batch) // self.per_video) if v % self.world == self.rank]
+
     @torch.no_grad()
     def ingest(self, gathered: torch.Tensor) -> List[Tuple[int, torch.Tensor]]:
         """Append one global batch of feature rows (stream order) to the ring and score every video
@@ -181,10 +190,9 @@ class ExtractScoreStream:
             raise ValueError(f"expected {self.global_batch} rows per global batch, got {gathered.shape[0]}")
         start = self.pos % self.ring_rows
         self.ring[start : start + self.global_batch].copy_(gathered)
-        first_done = self.pos // self.per_video  # videos complete before this batch
+        mine = self._videos_completing()
         self.pos += self.global_batch
         scored = []
-        mine = [v for v in range(first_done, self.pos // self.per_video) if v % self.world == self.rank]
         hook, self._after_ring_read = self._after_ring_read, None
         for v in mine:
             r0 = (v * self.per_video) % self.ring_rows
@@ -200,6 +208,14 @@ class ExtractScoreStream:
         (runner.py:42-50): add magnitude channel, (1, T, 10, 2049) -> (1, 10, T, 2049), eval forward."""
         self.videos_scored += 1
         if self.use_graph and feats.is_cuda and not self.scorer.training:
+            # a captured graph holds raw pointers to the cached packed weights: any change of the parameters (optimizer step,
+            # load_state_dict) must force a re-capture, or a replay reads stale / freed operands
+            from . import mgfn_ops
+
+            stamp = (mgfn_ops._EPOCH,) + tuple((p.data_ptr(), p._version) for p in self.scorer.parameters())
+            if stamp != getattr(self, "_graphs_stamp", None):
+                self._graphs.clear()
+                self._graphs_stamp = stamp
             key = tuple(feats.shape)
             entry = self._graphs.get(key)
             if entry is None:

@@ -41,10 +41,15 @@ class VideoAnomalyDetectionRunner:
         return self
 
     # runner.py:29-39 -- normal batch first, abnormal second
-    def training_step(self, batch, batch_idx) -> torch.Tensor:
+    @staticmethod
+    def training_batch(batch) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """(video (2B,10,T,C+1), abnormal_labels, normal_labels): the model inputs training_step assembles."""
         ninputs, ainputs = batch
-        inputs = torch.cat((ninputs["feature"], ainputs["feature"]), dim=0)
-        outputs = self.model(video=inputs, abnormal_labels=ainputs["anomaly"], normal_labels=ninputs["anomaly"])
+        return torch.cat((ninputs["feature"], ainputs["feature"]), dim=0), ainputs["anomaly"], ninputs["anomaly"]
+
+    def training_step(self, batch, batch_idx) -> torch.Tensor:
+        inputs, abnormal, normal = self.training_batch(batch)
+        outputs = self.model(video=inputs, abnormal_labels=abnormal, normal_labels=normal)
         self.log("train_loss", outputs.loss)
         return outputs.loss
 
@@ -63,8 +68,10 @@ class VideoAnomalyDetectionRunner:
         params = list(self.model.parameters())
         # same update rule as the reference's torch.optim.Adam; on GPU parameters torch's fused implementation (a few launches
         # instead of ~25 multi-tensor ones: 0.73 -> 0.3 ms of the 19-ms step)
+        # and with its step counters on the device (capturable): the whole step can then be replayed as one HIP graph
         fused = bool(params) and all(p.is_cuda for p in params)
-        return [torch.optim.Adam(params, lr=float(opt["learning_rate"]), weight_decay=float(opt["weight_decay"]), fused=fused)]
+        return [torch.optim.Adam(params, lr=float(opt["learning_rate"]), weight_decay=float(opt["weight_decay"]), fused=fused,
+                                 capturable=fused)]
 
     # runner.py:62-90 (metrics; the matplotlib/wandb chart is out of scope)
     def on_validation_epoch_end(self) -> Dict[str, float]:
@@ -130,11 +137,18 @@ class LearningRateMonitor:
         return {"lr-Adam": optimizer.param_groups[0]["lr"]}
 
 
+LIGHTNING_LAYOUT_VERSION = "2.0.0"  # the checkpoint layout written below (no migration needed by lightning >= 2.0)
+
+
 def checkpoint_state(runner: "VideoAnomalyDetectionRunner", optimizer, epoch: int, global_step: int, metrics_: Dict[str, float]) -> Dict[str, Any]:
     """A checkpoint in the key layout lightning.pytorch.ModelCheckpoint writes for the reference's LightningModule
     (`self.model = model`, runner.py:21-24): `state_dict` with the `model.` prefix, `optimizer_states`, `epoch`,
-    `global_step`, `hyper_parameters` -- so files move between the reference and this trainer in both directions."""
+    `global_step`, `hyper_parameters`, plus the keys Lightning's loader reads before anything else
+    (`pytorch-lightning_version` for its migration step, `loops`, `callbacks`).  Reference -> here is tested
+    (tests/test_hip_train.py); here -> Lightning is by construction only: Lightning is not installed in this image, the key set
+    is checked by tests/test_capi_and_host.py::test_checkpoint_carries_the_keys_lightning_reads."""
     return {
+        "pytorch-lightning_version": LIGHTNING_LAYOUT_VERSION, "loops": {}, "callbacks": {},
         "epoch": epoch, "global_step": global_step,
         "state_dict": {"model." + k: v for k, v in runner.model.state_dict().items()},
         "optimizer_states": [optimizer.state_dict()], "lr_schedulers": [],
@@ -246,6 +260,15 @@ class Trainer:
             ckpt = load_checkpoint(ckpt_path, runner, optimizer)
             first_epoch = int(ckpt.get("epoch", -1)) + 1
             self.global_step = int(ckpt.get("global_step", 0))
+        # the step as one HIP graph once the (fixed) batch shape has been seen a few times (train_graph.py); ADV_TRAIN_GRAPH=0:
+        # always the eager loop
+        graphed = None
+        if (os.environ.get("ADV_TRAIN_GRAPH", "1") == "1" and hasattr(runner, "training_batch")
+                and all(g.get("capturable", False) for g in optimizer.param_groups)):
+            from .train_graph import GraphedTrainStep
+
+            graphed = GraphedTrainStep(runner.model, optimizer, eager_steps=3, clip_grad_norm=self.gradient_clip_val)
+        self.graphed_step = graphed
         for epoch in range(first_epoch, self.max_epochs):
             runner.model.train()
             nloader, aloader = runner.train_dataloader()
@@ -253,13 +276,16 @@ class Trainer:
                 if 0 <= self.max_steps <= self.global_step:
                     break
                 batch = _to_device(batch, self.device)
-                optimizer.zero_grad(set_to_none=True)
-                loss = runner.training_step(batch, batch_idx)
-                loss.backward()
-                if self.gradient_clip_val:
-                    torch.nn.utils.clip_grad_norm_(runner.model.parameters(), self.gradient_clip_val)
-                optimizer.step()
-                mgfn_ops.invalidate_caches()  # (fused optimizers do not move version counters)
+                if graphed is not None:
+                    runner.log("train_loss", graphed(*runner.training_batch(batch)))
+                else:
+                    optimizer.zero_grad(set_to_none=True)
+                    loss = runner.training_step(batch, batch_idx)
+                    loss.backward()
+                    if self.gradient_clip_val:
+                        torch.nn.utils.clip_grad_norm_(runner.model.parameters(), self.gradient_clip_val)
+                    optimizer.step()
+                    mgfn_ops.invalidate_caches()  # (fused optimizers do not move version counters)
                 self.global_step += 1
                 if self.global_step % self.log_every_n_steps == 0:
                     m = {"train_loss": runner.logged["train_loss"], "epoch": epoch}

@@ -1,0 +1,92 @@
+"""One MGFN training step -- zero_grad -> forward -> four losses -> backward -> Adam -- replayed as ONE HIP graph.
+
+The eager step issues ~600 launches from Python autograd (the hand-written GEMM / LayerNorm / MIL / loss kernels through
+ctypes, plus the torch ops of stage 0 and the attention einsums): on a slow host the step is bound by that issue loop, not
+by the GPU (22.0 ms driver-timed against 17.5-18.7 ms on a faster host, same kernels).  The runner feeds a fixed
+`(2B, 10, 32, 2049)` shape (/root/reference/src/runner.py:29-39, configs/data: batch_size 16), so after a few eager steps
+the step is captured once (torch.cuda.CUDAGraph: every launch of this package goes to torch's current stream, nothing
+inside allocates or synchronises outside torch's allocator) and replayed with the batch copied into static buffers:
+
+  * same kernels, same order, same arithmetic as the eager step -- the graph only removes the host from the loop;
+  * the weight re-pack of every differentiated forward (mgfn_ops.pack_kc_cached(fresh=True)) is captured with it, so a
+    replay always packs the live parameters; `mgfn_ops.invalidate_caches()` runs after every replay for the inference
+    caches, as after an eager optimizer step;
+  * dropout masks of the MIL head come from torch's graph-safe Philox state: a different mask every replay;
+  * weight gradients and bias gradients run on a side stream inside the captured graph (mgfn_ops.overlapped_backward):
+    forked off the `dX` chain, joined before the optimizer -- the graph keeps that concurrency.
+
+Adam must be created with `capturable=True` (its step counters live on the device).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+
+from . import mgfn_ops
+
+
+class GraphedTrainStep:
+    """step(video (2B,10,T,C+1), abnormal_labels (B,), normal_labels (B,)) -> loss (a static device tensor, overwritten by
+    the next call).  The first `eager_steps` calls run eagerly (they are real training steps and warm every lazily built
+    operand); the next call captures and replays; a call with other shapes falls back to the eager step."""
+
+    def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, eager_steps: int = 3,
+                 clip_grad_norm: Optional[float] = None, overlap: bool = True,
+                 after_step: Optional[Callable[[], None]] = None):
+        for g in optimizer.param_groups:
+            if not g.get("capturable", False):
+                raise ValueError("GraphedTrainStep needs an optimizer created with capturable=True (device-side step counters)")
+        self.model, self.optimizer = model, optimizer
+        self.eager_left = eager_steps
+        self.clip, self.overlap = clip_grad_norm, overlap
+        self.after_step = after_step
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.static: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
+        self.loss: Optional[torch.Tensor] = None
+        self.replays = 0
+        if overlap and torch.cuda.is_available():
+            mgfn_ops.ensure_side_stream()  # (streams cannot be created inside a capture)
+
+    def _step(self, video, al, nl) -> torch.Tensor:
+        self.optimizer.zero_grad(set_to_none=True)
+        with mgfn_ops.overlapped_backward(self.overlap):
+            loss = self.model(video=video, abnormal_labels=al, normal_labels=nl).loss
+            loss.backward()
+        if self.clip:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
+        self.optimizer.step()
+        return loss
+
+    def _finish(self) -> None:
+        mgfn_ops.invalidate_caches()  # (fused / captured optimizers do not move version counters)
+        if self.after_step is not None:
+            self.after_step()
+
+    def __call__(self, video: torch.Tensor, abnormal_labels: torch.Tensor, normal_labels: torch.Tensor) -> torch.Tensor:
+        key = (tuple(video.shape), tuple(abnormal_labels.shape), tuple(normal_labels.shape))
+        if self.graph is not None and key == self._key:
+            for dst, src in zip(self.static, (video, abnormal_labels, normal_labels)):
+                dst.copy_(src)
+            self.graph.replay()
+            self.replays += 1
+            self._finish()
+            return self.loss
+        if self.eager_left > 0 or self.graph is not None or not self.model.training:
+            self.eager_left -= 1
+            loss = self._step(video, abnormal_labels, normal_labels).detach()
+            self._finish()
+            return loss
+        # capture (records, does not run), then replay on this batch
+        self._key = key
+        self.static = tuple(t.detach().clone() for t in (video, abnormal_labels, normal_labels))
+        torch.cuda.synchronize()
+        self.optimizer.zero_grad(set_to_none=True)  # the captured backward allocates the gradients in the graph's pool
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = self._step(*self.static)
+        self.graph, self.loss = graph, loss.detach()
+        self.graph.replay()
+        self.replays += 1
+        self._finish()
+        return self.loss

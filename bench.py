@@ -94,6 +94,19 @@ def launch_ranks(n: int, argv) -> int:
     return 0
 
 
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(budget_s: float = 12.0):
     """The oracle (CPU restatement of the reference's path, pinned by tests/golden) timed on this
     host's cores on a bounded sample: config 1 of BASELINE.json (8 crop-clips per I3D forward) plus
@@ -134,7 +147,7 @@ def cpu_baseline(budget_s: float = 12.0):
         t_video = (time.perf_counter() - t) / 3
     per_clip = t_clip + t_video / 320.0
     return {
-        "value": round(1.0 / per_clip, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+        "value": round(1.0 / per_clip, 3), "unit": "clips/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
         "sample": f"{reps} x I3D oracle forward of 8 crop-clips (3x16x224x224, median) + MGFN oracle eval of one 32x10 video / 320",
         "i3d_ms_per_8_clips": round(times[len(times) // 2] * 1e3, 2), "mgfn_ms_per_video": round(t_video * 1e3, 2),
     }
@@ -147,7 +160,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=32, help="crop-clips per GPU per step (BASELINE config 2: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--h2d", action="store_true", help="also time a PCIe-inclusive variant (host fp32 input each step)")
+    ap.add_argument("--h2d", action="store_true", help="the full set of PCIe-inclusive legs (batch 40, two-pass and uint8-crop variants); "
+                    "the two headline legs (resized uint8 frames, fp32 crops) run by default at N=1")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the default PCIe-inclusive legs")
     ap.add_argument("--sustain-s", type=float, default=3.0, help="seconds of back-to-back steps after the K timed ones (the `sustained` record: DVFS shows here)")
     ap.add_argument("--no-mgfn-train", action="store_true", help="skip the MGFN training-step record (config 4)")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous only (gloo, no GPU): checks the rank launch + result relay")
@@ -162,9 +177,14 @@ def main():
     from anomaly_detection_on_video_amd.pipeline import ExtractScoreStream
     from anomaly_detection_on_video_amd.weights import synth_i3d_state_dict, synth_module_state_dict
 
+    from anomaly_detection_on_video_amd import ops as aops
+
     rank, local_rank, world = adist.env_world()
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    if aops.ARITH != "f32":  # the line below prices the step against the fp32 MFMA peak and says dtype f32: refuse anything else
+        raise SystemExit(f"bench.py: ADV_ARITH={aops.ARITH!r} switches conv kernels to split-bf16 arithmetic; the reported line is "
+                         "the exact-fp32 path (dtype f32, 157.3 TFLOP/s roofline) -- unset ADV_ARITH")
     if args.dry_run:  # no GPU call anywhere on this path
         adist.init_process_group("gloo")
         n = torch.ones(1)
@@ -223,10 +243,15 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     backbone.forward = orig_forward
+    rank_elapsed = [elapsed]
+    backend_observed, world_observed = "none (single process)", 1
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.zeros(world, device=dev, dtype=torch.float64)
+        t[rank] = elapsed
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)  # every rank's own clock around the same K steps
+        rank_elapsed = [float(v) for v in t.tolist()]
+        elapsed = max(rank_elapsed)
+        backend_observed, world_observed = torch.distributed.get_backend(), torch.distributed.get_world_size()
 
     # backbone duration per step from the HIP events recorded on the launch stream(s).
     #  - one stream, one lane: [start, (pool start, end) x3, end] per step -> conv stack = span minus the pool launches;
@@ -270,35 +295,89 @@ def main():
                      "ms_per_step": round(sus / n_sus * 1e3, 4),
                      "frac_of_mfma_peak_whole_step": round(sus_clips / world * GFLOP_PER_CLIP / 1e3 / PEAK_F32_MFMA_TFLOPS, 4)}
 
-    # BASELINE config 4: one MGFN training step (32,10,32,2049): forward + 4 losses + backward + Adam, rank 0 at N=1
+    # BASELINE config 4: one MGFN training step (32,10,32,2049): forward + 4 losses + backward + Adam, rank 0 at N=1 --
+    # the step the runner's Trainer executes: captured once as a HIP graph (train_graph.GraphedTrainStep), replayed per batch
     mgfn_train = None
     if world == 1 and not args.no_mgfn_train:
+        from anomaly_detection_on_video_amd.train_graph import GraphedTrainStep
+
         scorer.train()
-        opt = torch.optim.Adam(scorer.parameters(), lr=1e-3, weight_decay=5e-4, fused=True)  # (the runner's choice on GPU parameters: one fused update launch per chunk)
+        # (the runner's optimizer on GPU parameters, runner.configure_optimizers: fused update, device-side step counters)
+        opt = torch.optim.Adam(scorer.parameters(), lr=1e-3, weight_decay=5e-4, fused=True, capturable=True)
         vb = torch.rand(32, 10, 32, 2048, device=dev, generator=gen) * 3
         vb = torch.cat([vb, vb.norm(dim=3, keepdim=True)], dim=3)
         al, nl = torch.ones(16, device=dev), torch.zeros(16, device=dev)
+        step = GraphedTrainStep(scorer, opt, eager_steps=3)
 
-        def train_step():
-            opt.zero_grad(set_to_none=True)
-            scorer(video=vb, abnormal_labels=al, normal_labels=nl).loss.backward()
-            opt.step()
+        def timed_steps(n):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                step(vb, al, nl)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / n * 1e3
 
-        for _ in range(3):
-            train_step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(10):
-            train_step()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t1) / 10 * 1e3
+        timed_steps(3)                # the eager steps (warm every lazily built operand)
+        eager_ms = None
+        if os.environ.get("ADV_TRAIN_GRAPH", "1") == "1":
+            step.eager_left = 10
+            eager_ms = timed_steps(10)    # the same step issued launch by launch from Python
+            timed_steps(2)                # capture + first replays
+            ms = timed_steps(20)
+            assert step.graph is not None and step.replays >= 22
+        else:
+            step.eager_left = 1 << 30
+            ms = timed_steps(10)
         tflop = 3 * 2 * 293.3e9 / 1e12  # forward 293.3 GMAC, backward = 2 x forward
         mgfn_train = {"workload": "run.py MIL scorer + losses, fwd+bwd+Adam, (32,10,32,2049) fp32, 1 GPU", "ms_per_step": round(ms, 3),
+                      "mode": "one HIP graph replay per step (train_graph.GraphedTrainStep, what runner.Trainer runs)" if step.graph is not None else "eager",
+                      "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 3),
                       "tflop_per_step": round(tflop, 3), "achieved_tflops": round(tflop / ms * 1e3, 2),
                       "frac_of_f32_mfma_peak": round(tflop / ms * 1e3 / PEAK_F32_MFMA_TFLOPS, 4)}
+        del step, opt
         scorer.eval()
+        scorer.zero_grad(set_to_none=True)
 
     h2d = h2d_u8 = h2d_frames = None
+    pcie = None
+    if world == 1 and not args.no_pcie and not args.h2d:
+        # SURVEY 8(d) cfg 1-2: the end-to-end rate INCLUDING the host -> device copy, labelled separately (never `value`).
+        # Pinned host buffers, the copy issued on the step's lane so PCIe overlaps the other lanes' compute; 3 + K steps each.
+        from anomaly_detection_on_video_amd.pipeline import FrameCrops
+
+        def pcie_leg(st, host, prep, batch):
+            for _ in range(3):
+                st.step_async(host, prepare=prep)
+            st.drain()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                st.step_async(host, prepare=prep)
+            st.drain()
+            torch.cuda.synchronize()
+            return batch * args.steps / (time.perf_counter() - t1)
+
+        # (a) what a decoder + GroupResize(256) hand over: 4 clips = 64 resized uint8 frames per step; the stem kernel reads the
+        #     pixels itself (TenCrop + float + normalise in its load stage) -> 40 crop-clips; beside it the resident rate of
+        #     that same 40-crop-clip batch
+        fr = torch.randint(0, 256, (64, 256, 341, 3), dtype=torch.uint8).pin_memory()
+        stream40 = ExtractScoreStream(backbone, scorer, clips_per_video=32, ncrops=10, local_batch=40, world=1, rank=0)
+        x40 = torch.randn((40, 3, 16, 224, 224), device=dev, generator=gen)
+        res40 = pcie_leg(stream40, x40, None, 40)
+        frames40 = pcie_leg(stream40, fr, lambda h: FrameCrops(h.to(dev, non_blocking=True), 0, 40), 40)
+        del x40, stream40
+        # (b) the reference's own hand-over: fp32 crop-clips from the host (extract_features.py:83-88), batch 32
+        xh = x.cpu().pin_memory()
+        fp32_32 = pcie_leg(stream, xh, lambda h: h.to(dev, non_blocking=True), args.batch)
+        pcie = {
+            "note": "host buffers every step (pinned), copy on the step's lane; never the headline `value`",
+            "resized_frames_u8": {"clips_per_s": round(frames40, 2), "crop_clips_per_step": 40, "h2d_bytes_per_step": fr.numel(),
+                                  "resident_same_batch_clips_per_s": round(res40, 2), "ratio_to_resident": round(frames40 / res40, 4),
+                                  "input": "64 uint8 frames 256x341x3 (4 clips) -> TenCrop/normalise inside the stem kernel"},
+            "fp32_crops": {"clips_per_s": round(fp32_32, 2), "crop_clips_per_step": args.batch, "h2d_bytes_per_step": xh.numel() * 4,
+                           "ratio_to_resident": None, "input": "fp32 (32,3,16,224,224) host tensor, the reference's hand-over"},
+        }
+        del xh, fr
     if args.h2d and world == 1:  # single-process extra; with N > 1 a rank-0-only step would leave the collective hanging
         # host buffers every step: the copy (and the uint8 pre-processing) is issued on the step's lane, so PCIe
         # transfers overlap the other lanes' compute
@@ -361,6 +440,10 @@ def main():
                 "clip": "3x16x224x224 fp32", "local_batch": args.batch, "global_batch": args.batch * world,
                 "clips_per_video": 32, "ncrops": 10, "videos_scored_rank0": stream.videos_scored - videos_before,
                 "weights": "deterministic synthetic (no network)", "parallelism": f"dp{world}",
+                "backend": backend_observed, "world_size_observed": world_observed,  # what torch.distributed reports, not what was asked for
+                "rank_clips_per_s_min": round(args.batch * args.steps / max(rank_elapsed), 2),
+                "rank_clips_per_s_max": round(args.batch * args.steps / min(rank_elapsed), 2),
+                "arith": aops.ARITH,
             },
             "roofline": {
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -377,6 +460,9 @@ def main():
             out["sustained"] = sustained
         if mgfn_train is not None:
             out["mgfn_train_step"] = mgfn_train
+        if pcie is not None:
+            pcie["fp32_crops"]["ratio_to_resident"] = round(pcie["fp32_crops"]["clips_per_s"] / (total_clips / elapsed), 4)
+            out["pcie_inclusive"] = pcie
         if h2d is not None:
             out["pcie_inclusive_clips_per_s"] = round(h2d, 2)
             out["pcie_inclusive_uint8_clips_per_s"] = round(h2d_u8, 2)

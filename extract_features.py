@@ -28,10 +28,13 @@ def synthetic_sources(n_videos: int, seed: int = 0):
         yield name, (lambda n=n_clips, s=seed + i: torch.randn((n, 10, 16, 3, 224, 224), generator=torch.Generator().manual_seed(s)))
 
 
-def main(outdir: str = "ucf_crime", videos: int = 4, weights: str = None, synthetic_weights: bool = False):
+def main(outdir: str = "ucf_crime", videos: int = 4, weights: str = None, synthetic_weights: bool = False,
+         model_name: str = "i3d_8x8_r50"):
+    """`model_name` defaults to the reference's (extract_features.py:34,46); that variant is parity-unpinned here (a warning
+    says so) -- `--model-name tushar-n-baseline` is the I3Res50 pinned against the reference."""
     if synthetic_weights:
         os.environ["ADV_I3D_SYNTHETIC"] = "1"
-    model, _device = load_feature_extraction_model(state_dict_path=weights, check_model_size=True)
+    model, _device = load_feature_extraction_model(model_name, state_dict_path=weights, check_model_size=True)
     outpath = os.path.join(outdir, "anomaly_features", "train")
     extract(synthetic_sources(videos), model, outpath)
     seg_length = 32
@@ -44,5 +47,7 @@ if __name__ == "__main__":
     ap.add_argument("--videos", type=int, default=4)
     ap.add_argument("--weights", default=None)
     ap.add_argument("--synthetic-weights", action="store_true")
+    ap.add_argument("--model-name", default="i3d_8x8_r50", choices=["i3d_8x8_r50", "tushar-n-baseline"],
+                    help="the reference's default is i3d_8x8_r50 (parity-unpinned here); tushar-n-baseline = the pinned in-repo I3Res50")
     a = ap.parse_args()
-    main(a.outdir, a.videos, a.weights, a.synthetic_weights)
+    main(a.outdir, a.videos, a.weights, a.synthetic_weights, a.model_name)

@@ -10,8 +10,40 @@ if REPO not in sys.path:
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
 
+_LAUNCHER = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # started BEFORE the first GPU call of this process (pytest_collection_modifyitems below): see tests/_launcher.py
+    global _LAUNCHER
+    if _LAUNCHER is None and os.path.exists("/dev/kfd"):
+        import subprocess
+
+        _LAUNCHER = subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "_launcher.py")], stdin=subprocess.PIPE,
+                                     stdout=subprocess.PIPE, text=True, bufsize=1)
+
+
+def pytest_unconfigure(config):
+    global _LAUNCHER
+    if _LAUNCHER is not None:
+        try:
+            _LAUNCHER.stdin.close()
+            _LAUNCHER.wait(timeout=30)
+        except Exception:
+            _LAUNCHER.kill()
+        _LAUNCHER = None
+
+
+def launch_fresh(argv, env=None, unset=(), timeout=600, cwd=None):
+    """Run `argv` as a fresh program through the GPU-free helper process; -> {"rc", "stdout", "stderr"}."""
+    import json
+
+    if _LAUNCHER is None or _LAUNCHER.poll() is not None:
+        raise RuntimeError("the launcher helper is not running (no /dev/kfd at session start?)")
+    _LAUNCHER.stdin.write(json.dumps({"argv": list(argv), "env": dict(env or {}), "unset": list(unset), "timeout": timeout, "cwd": cwd or REPO}) + "\n")
+    _LAUNCHER.stdin.flush()
+    return json.loads(_LAUNCHER.stdout.readline())
 
 
 def pytest_collection_modifyitems(config, items):

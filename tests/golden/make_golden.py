@@ -336,8 +336,39 @@ def golden_host():
     print("auc.npz", auc(fpr, tpr), auc(rec, prec))
 
 
+# ------------------------------------------------------------------------------- clip pre-processing
+def golden_preproc():
+    """The reference's own GroupStandardizationTenCrop / LoopPad (src/gtransforms.py:57-73, 115-132) and the two layout
+    permutes (src/dataset.py:195, extract_features.py:83) on uint8-valued input.  The frames are exactly crop-sized, so
+    torchvision's five crops all coincide with the frame and the other five with its mirror image: no crop GEOMETRY (which
+    is torchvision's, absent here) enters -- what is pinned is the arithmetic (sub then div, fp32, in place), the padding
+    rule and the (clip, crop, C, T, H, W) layout the backbone receives."""
+    _video_io_placeholders()
+    from src import gtransforms as g  # reference
+
+    std, pad = g.GroupStandardizationTenCrop(), g.LoopPad(max_len=16)
+    out = {}
+    for length in (5, 8, 16):
+        frames = (synth_tensor(f"preproc.frames/{length}", (length, 8, 8, 3), scale=0.5, offset=0.5) * 255).round().clamp(0, 255).to(torch.uint8)
+        chw = frames.permute(0, 3, 1, 2)
+        # what GroupTenCrop + ToTensorTenCrop (gtransforms.py:20-38) hand on for a crop-sized frame: (len, 10, C, h, w) floats
+        crops = torch.stack([chw] * 5 + [chw.flip(-1)] * 5, dim=1).float()
+        item = pad(std(crops.clone())).permute(1, 0, 2, 3, 4)        # TenCropVideoFrameDataset.__getitem__, dataset.py:191-195
+        batch = item.unsqueeze(0).permute(0, 1, 3, 2, 4, 5)          # _extract, extract_features.py:81-83
+        out[f"frames_{length}"] = frames.numpy()
+        out[f"clip_{length}"] = batch.contiguous().numpy()           # (1, 10, 3, 16, 8, 8)
+        out[f"looppad_index_{length}"] = pad(torch.arange(length, dtype=torch.float32).view(length, 1)).view(-1).numpy()
+    x = (synth_tensor("preproc.std_in", (5, 10, 3, 8, 8), scale=0.5, offset=0.5) * 255).round().clamp(0, 255)
+    out["std_in"] = x.numpy().copy()
+    out["std_out"] = std(x.clone()).numpy()
+    np.savez_compressed(os.path.join(HERE, "preproc.npz"), **out)
+    print("preproc.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["i3d", "nonlocal", "mgfn", "host"]
+    which = sys.argv[1:] or ["i3d", "nonlocal", "mgfn", "host", "preproc"]
+    if "preproc" in which:
+        golden_preproc()
     if "i3d" in which:
         golden_i3d()
     if "nonlocal" in which:

@@ -283,3 +283,23 @@ def test_stream_ring_orders_videos_like_the_reference():
                 assert torch.equal(ids, torch.arange(20 * v, 20 * v + 20, dtype=torch.float32).view(4, 5))
             with pytest.raises(ValueError):
                 streams[0].ingest(torch.zeros(gb + 1, 8))
+
+
+def test_checkpoint_carries_the_keys_lightning_reads():
+    """A last.ckpt written here must be loadable by the reference's Lightning trainer: its loader indexes
+    `pytorch-lightning_version` unconditionally (migration step), then reads `state_dict` (keys prefixed `model.`, the
+    LightningModule holds the net as `self.model`: /root/reference/src/runner.py:21-24), `optimizer_states`,
+    `lr_schedulers`, `epoch`, `global_step`, `loops`, `callbacks`.  Lightning itself is absent from this image, so the key
+    set is what is checked."""
+    from anomaly_detection_on_video_amd.runner import VideoAnomalyDetectionRunner, checkpoint_state
+
+    net = torch.nn.Linear(3, 2)
+    runner = VideoAnomalyDetectionRunner(net, {"learning_rate": 1e-3, "weight_decay": 5e-4}, {"frames_per_clip": 16})
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    st = checkpoint_state(runner, opt, epoch=3, global_step=17, metrics_={"valid/rec_auc": 0.5})
+    for key in ("pytorch-lightning_version", "state_dict", "optimizer_states", "lr_schedulers", "epoch", "global_step", "loops", "callbacks",
+                "hyper_parameters"):
+        assert key in st, key
+    assert isinstance(st["pytorch-lightning_version"], str) and st["pytorch-lightning_version"].split(".")[0] == "2"
+    assert set(st["state_dict"]) == {"model.weight", "model.bias"} and st["epoch"] == 3 and st["global_step"] == 17
+    assert isinstance(st["callbacks"], dict) and isinstance(st["loops"], dict) and len(st["optimizer_states"]) == 1

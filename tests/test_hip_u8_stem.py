@@ -174,3 +174,39 @@ def test_stream_steps_from_frames_match_steps_from_crops(form):
         assert rel_err(fa[i], fb[i]) < 1e-5, f"step {i}"
         assert torch.equal(fa[i], fa[(i + 3) % 6])
     assert a.videos_scored == b.videos_scored == 3  # 6 steps x 2 clips = 12 clips = 3 videos of 4
+
+
+@pytest.mark.parametrize("length", [5, 8, 16])
+def test_tencrop_normalize_pass_vs_reference_golden(length):
+    """mil_ops.tencrop_normalize_u8 against the reference's own GroupStandardizationTenCrop + LoopPad + permutes (goldens made
+    by tests/golden/make_golden.py from src/gtransforms.py:57-73,115-132, src/dataset.py:195, extract_features.py:83), bit
+    for bit.  Crop-sized frames, so the (unpinned, torchvision) crop offsets play no part."""
+    import os
+
+    from conftest import GOLDEN
+    from anomaly_detection_on_video_amd import mil_ops
+
+    g = np.load(os.path.join(GOLDEN, "preproc.npz"))
+    got = mil_ops.tencrop_normalize_u8(torch.from_numpy(g[f"frames_{length}"]).to(_dev()), 16, 8)
+    assert got.shape == (10, 3, 16, 8, 8)
+    assert np.array_equal(got.cpu().numpy(), g[f"clip_{length}"][0])
+
+
+def test_u8_stem_at_the_reference_geometry_vs_oracle(form):
+    """The border-class table at full size against the CPU oracle (not against another HIP path): 2 clips of 256 x 340
+    frames, crop 224 -> 20 crop-clips through numpy TenCrop -> torch conv / BN / ReLU -> max_pool3d
+    (/root/reference/src/i3d.py:303-306)."""
+    from anomaly_detection_on_video_amd import ops
+    from oracle import host_oracle, i3d_oracle
+
+    pc, (wt, g, be, mu, var) = _stem()
+    frames = _frames(77, (32, 256, 340, 3))
+    fd = torch.from_numpy(frames).to(_dev())
+    got = ops.conv3d_u8_tencrop_bn_relu_maxpool233(fd, pc, 0, 20, 16, 224).cpu()
+    x = torch.from_numpy(host_oracle.ten_crop_clips(frames, 16, 224)).reshape(20, 3, 16, 224, 224)
+    torch.set_num_threads(min(16, torch.get_num_threads() or 16))
+    want = torch.cat([torch.nn.functional.max_pool3d(i3d_oracle.conv_bn_act(x[i : i + 5], wt, g, be, mu, var, (2, 2, 2), (2, 3, 3), None, True),
+                                                     (2, 3, 3), (2, 2, 2)) for i in range(0, 20, 5)])
+    assert got.shape == want.shape == (20, 64, 4, 55, 55)
+    assert rel_err(got, want) < 2e-5
+    assert_close_elementwise(got, want)

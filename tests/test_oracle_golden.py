@@ -244,3 +244,26 @@ def test_i3d_with_nonlocal_blocks_oracle_vs_reference_golden():
     y = i3d_oracle.i3d_forward(synth_input((1, 3, 8, 112, 96), 7), sd)
     assert rel_err(y.reshape(1, 2048), g["feat_nl_small"]) < 1e-5
     assert np.isfinite(g["feat_nl_64"]).all() and float(np.abs(g["feat_nl_64"]).max()) > 0
+
+
+@pytest.mark.parametrize("length", [5, 8, 16])
+def test_clip_preprocessing_oracle_vs_reference_golden(length):
+    """host_oracle.ten_crop_clips against the reference's own GroupStandardizationTenCrop + LoopPad + the two permutes
+    (src/gtransforms.py:57-73,115-132; src/dataset.py:195; extract_features.py:83), bit for bit.  Crop-sized frames: no crop
+    geometry (torchvision's, absent) enters, only the arithmetic, the padding rule and the layout."""
+    from oracle import host_oracle
+
+    g = np.load(os.path.join(GOLDEN, "preproc.npz"))
+    got = host_oracle.ten_crop_clips(g[f"frames_{length}"], 16, 8)
+    assert got.shape == g[f"clip_{length}"].shape == (1, 10, 3, 16, 8, 8)
+    assert np.array_equal(got, g[f"clip_{length}"])
+    # LoopPad: slot i of the padded clip holds source frame i % length (lengths that divide 16 or not)
+    assert np.array_equal(g[f"looppad_index_{length}"], np.arange(16) % length)
+
+
+def test_standardisation_order_vs_reference_golden():
+    """(x - mean) / std as two fp32 operations in that order (`t.sub_(m).div_(s)`, gtransforms.py:69-72) -- not one fused
+    multiply-add, which rounds differently."""
+    g = np.load(os.path.join(GOLDEN, "preproc.npz"))
+    x = g["std_in"]
+    assert np.array_equal((x - np.float32(114.75)) / np.float32(57.375), g["std_out"])
