@@ -111,6 +111,7 @@ SIGNATURES = {
     "advhip_conv3d_bn_act_maxpool211_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _L, _P, _P, _P, _P, _P, _P, _L, _P]),
     "advhip_bgemm_f32": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P]),
     "advhip_gemm_nt_f32": (C.c_int, [_P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _L, _P]),
+    "advhip_gemm_nt_rowsum_f32": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _L, _I, _P]),
     "advhip_softmax_rows_f32": (C.c_int, [_P, _P, _L, _I, C.c_float, _P]),
     "advhip_conv3d_bn_act_ex_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _L, _P, _P, _P, _P, _P, _P, _L, C.POINTER(ConvEpilogue), _P, _L, _P]),
     "advhip_chan_stats_f32": (C.c_int, [_P, _P, _P, _I, _L, C.c_float, _P]),
@@ -123,6 +124,10 @@ SIGNATURES = {
     "advhip_chan_layernorm_bwd_f32": (C.c_int, [_P] * 8 + [_I, _L, C.c_float, _P]),
     "advhip_bn_rows_fwd_f32": (C.c_int, [_P] * 6 + [_I, _L, C.c_float, _P]),
     "advhip_bn_rows_bwd_f32": (C.c_int, [_P] * 8 + [_I, _L, C.c_float, _P]),
+    "advhip_bn_rows_fwd_running_f32": (C.c_int, [_P] * 8 + [C.c_float, _I, _L, C.c_float, _P]),
+    "advhip_bn_rows_bwd_add_f32": (C.c_int, [_P] * 9 + [_I, _L, C.c_float, _P]),
+    "advhip_chan_layernorm_bwd_add_f32": (C.c_int, [_P] * 8 + [_I, _L, C.c_float, _P]),
+    "advhip_conv1d_pack_weight_dx_f32": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "advhip_unfold3_f32": (C.c_int, [_P, _P, _I, _L, _I, _P]),
     "advhip_dwconv_t_fwd_f32": (C.c_int, [_P] * 4 + [_I, _I, _L, _I, _I, _P]),
     "advhip_dwconv_t_bwd_chunks": (_I, [_I, _L]),

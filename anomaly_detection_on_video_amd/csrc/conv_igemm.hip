@@ -1462,6 +1462,7 @@ struct GemmKKArgs {
   unsigned a_bytes, b_bytes;
   int tiles_m, tiles_n, splits;
   long long slab;       // elements between the outputs of consecutive K slices
+  float* rowsum;        // nullable [splits][M]: sum over the K slice of A[m][k] (the bias gradient beside dW = dY X^T)
 };
 
 template <int BM, int BN>
@@ -1523,6 +1524,14 @@ __global__ __launch_bounds__(256) void gemm_kk_dma_kernel(const GemmKKArgs g) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // row sums of A (db = sum_n dY[o][n] beside dW): the n-tile-0 workgroup of every m-tile already has each A row in its
+  // fragments -- lane (li, lg) holds k = 4 lg .. 4 lg + 3 of row 16 i + li -- so the waves of its first wave column add them up
+  // (FM x 4 VALU adds per k-tile beside FM x FN x 4 MFMAs) and fold the four lane groups at the end.
+  const bool do_rs = g.rowsum != nullptr && tile_n == 0 && wn == 0;  // (wave-uniform)
+  float rs[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) rs[i] = 0.f;
+
   const int nk_all = g.K / BK;
   const int kt0 = (nk_all * split) / g.splits, kt1 = (nk_all * (split + 1)) / g.splits;
   if (kt0 < kt1) issue(kt0, 0);
@@ -1548,8 +1557,22 @@ __global__ __launch_bounds__(256) void gemm_kk_dma_kernel(const GemmKKArgs g) {
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].v[e], fb[j].v[e], acc[i][j], 0, 0, 0);
+    if (do_rs) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) rs[i] += (fa[i].v[0] + fa[i].v[1]) + (fa[i].v[2] + fa[i].v[3]);
+    }
     __builtin_amdgcn_sched_barrier(0);
     stage ^= 1;
+  }
+  if (do_rs) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      float v = rs[i];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      const int m = m0 + wm * (BM / 2) + 16 * i + li;
+      if (lg == 0 && m < g.M) g.rowsum[(long long)split * g.M + m] = v;
+    }
   }
   // D[row = 4 lg + r][col = li] of fragment (i, j): m = m0 + wm*BM/2 + 16 i + 4 lg + r, n = n0 + wn*BN/2 + 16 j + li
   float* __restrict__ C = g.C + (long long)split * g.slab;
@@ -1801,6 +1824,17 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
+// The packed operand of a Conv1d's TRANSPOSED conv (its input gradient dX = conv1d(dY; W'), W'[c][o][j] = W[o][c][k-1-j]) straight
+// from the parameter w (Cout, Cin, k): wp[(o * k + j)][c] = w[o][c][k - 1 - j], zero rows above Cout * k.
+__global__ void pack_weight_dx_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int k, int Kpad) {
+  const long long total = (long long)Kpad * Cin;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / Cin), c = (int)(i % Cin);
+    const int o = row / k, j = row - o * k;
+    wp[i] = (o < Cout) ? w[((size_t)o * Cin + c) * k + (k - 1 - j)] : 0.f;
+  }
+}
+
 __global__ void build_ktab_kernel(int4* __restrict__ ktab, int kt, int kh, int kw, int K, int Kpad, int HW, int W,
                                   int THW) {
   const int taps = kt * kh * kw;
@@ -1943,6 +1977,15 @@ extern "C" int advhip_conv3d_pack_weight_f32(const advhip_conv3d_desc* d, const 
   const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
   hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, w_packed, d->Cout, K, Kpad);
   return check_launch("pack_weight");
+}
+
+extern "C" int advhip_conv1d_pack_weight_dx_f32(const float* w, float* w_packed, int32_t Cout, int32_t Cin, int32_t k, void* stream) {
+  ADVHIP_REQUIRE(w && w_packed && Cout > 0 && Cin > 0 && k > 0 && k <= 10, "pack_weight_dx: bad arguments");
+  const int Kpad = (Cout * k + 31) / 32 * 32;
+  const long long total = (long long)Kpad * Cin;
+  const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(pack_weight_dx_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, w_packed, Cout, Cin, k, Kpad);
+  return check_launch("pack_weight_dx");
 }
 
 extern "C" int advhip_conv3d_pack_weight_bf16x3(const advhip_conv3d_desc* d, const float* w, void* w_split, void* stream) {
@@ -2623,8 +2666,9 @@ extern "C" int advhip_conv3d_bn_act_maxpool211_f32(const advhip_conv3d_desc* d, 
 
 
 // ---- "NT" product of two k-contiguous operands (weight gradients of the GEMM-shaped MGFN layers) --------------------------
-extern "C" int advhip_gemm_nt_f32(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda,
-                                  int64_t ldb, int64_t ldc, int32_t splits, int64_t slab_stride, void* stream) {
+namespace advhip {
+static int gemm_nt_launch(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb,
+                          int64_t ldc, int32_t splits, int64_t slab_stride, int32_t tile, float* rowsum_a, void* stream) {
   ADVHIP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "gemm_nt: bad arguments");
   ADVHIP_REQUIRE(K % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0,
                  "gemm_nt: K=%d must be a multiple of 16 and the operands 16-byte aligned with row pitches that are multiples of 4", K);
@@ -2632,17 +2676,33 @@ extern "C" int advhip_gemm_nt_f32(const float* A, const float* B, float* C, int3
   const long long a_bytes = ((long long)(M - 1) * lda + K) * 4, b_bytes = ((long long)(N - 1) * ldb + K) * 4;
   ADVHIP_REQUIRE(a_bytes < 0xF0000000ll && b_bytes < 0xF0000000ll, "gemm_nt: operand above 3.75 GiB");
   ADVHIP_REQUIRE(splits >= 1 && splits <= K / 16 && (splits == 1 || slab_stride >= (long long)(M - 1) * ldc + N), "gemm_nt: bad split count %d", splits);
+  ADVHIP_REQUIRE(tile >= 0 && tile <= 3, "gemm_nt: tile id %d (0 auto, 1 64x64, 2 128x64, 3 128x128)", tile);
   GemmKKArgs g;
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
   g.lda = (int)lda; g.ldb = (int)ldb; g.ldc = (int)ldc;
   g.a_bytes = (unsigned)a_bytes; g.b_bytes = (unsigned)b_bytes;
-  g.splits = splits; g.slab = slab_stride;
-  const bool big = (long long)((M + 127) / 128) * ((N + 63) / 64) * splits >= 1536;
-  g.tiles_m = big ? (M + 127) / 128 : (M + 63) / 64;
-  g.tiles_n = (N + 63) / 64;
+  g.splits = splits; g.slab = slab_stride; g.rowsum = rowsum_a;
+  if (tile == 0) tile = ((long long)((M + 127) / 128) * ((N + 63) / 64) * splits >= 1536) ? 2 : 1;
+  const int bm = tile == 1 ? 64 : 128, bn = tile == 3 ? 128 : 64;
+  g.tiles_m = (M + bm - 1) / bm;
+  g.tiles_n = (N + bn - 1) / bn;
   const long long blocks = (long long)g.tiles_m * g.tiles_n * splits;
   ADVHIP_REQUIRE(blocks < (1ll << 31), "gemm_nt: too many tiles");
-  if (big) hipLaunchKernelGGL((gemm_kk_dma_kernel<128, 64>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
-  else hipLaunchKernelGGL((gemm_kk_dma_kernel<64, 64>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+  const dim3 grid((unsigned)blocks);
+  if (tile == 3) hipLaunchKernelGGL((gemm_kk_dma_kernel<128, 128>), grid, dim3(256), 0, (hipStream_t)stream, g);
+  else if (tile == 2) hipLaunchKernelGGL((gemm_kk_dma_kernel<128, 64>), grid, dim3(256), 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL((gemm_kk_dma_kernel<64, 64>), grid, dim3(256), 0, (hipStream_t)stream, g);
   return check_launch("gemm_nt");
+}
+}  // namespace advhip
+
+extern "C" int advhip_gemm_nt_f32(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda,
+                                  int64_t ldb, int64_t ldc, int32_t splits, int64_t slab_stride, void* stream) {
+  return advhip::gemm_nt_launch(A, B, C, M, N, K, lda, ldb, ldc, splits, slab_stride, 0, nullptr, stream);
+}
+
+extern "C" int advhip_gemm_nt_rowsum_f32(const float* A, const float* B, float* C, float* rowsum_a, int32_t M, int32_t N, int32_t K,
+                                         int64_t lda, int64_t ldb, int64_t ldc, int32_t splits, int64_t slab_stride, int32_t tile,
+                                         void* stream) {
+  return advhip::gemm_nt_launch(A, B, C, M, N, K, lda, ldb, ldc, splits, slab_stride, tile, rowsum_a, stream);
 }

@@ -104,7 +104,10 @@ __global__ __launch_bounds__(LN_THREADS) void chan_layernorm_bwd_kernel(const fl
                                                                         const float* __restrict__ g, const float* __restrict__ mu,
                                                                         const float* __restrict__ rs, float* __restrict__ dx,
                                                                         float* __restrict__ pg, float* __restrict__ pb, int Cc, long long N,
-                                                                        float eps) {
+                                                                        float eps, const float* __restrict__ add, long long prow) {
+  // `add` (nullable, dx's shape): dx = LayerNorm backward + add -- the gradient of the block's skip connection
+  // (y = f(LN(x)) + x: dL/dx = LN'(...) + dL/dy) without autograd's separate add over the activation.
+  // `prow`: row pitch of the partial-sum matrices (C when pg / pb are separate, 2C when they are the halves of one matrix)
   __shared__ float part[2][LN_GROUPS][LN_COLS];
   const int p = threadIdx.x % LN_COLS, grp = threadIdx.x / LN_COLS;
   const long long n = blockIdx.x * (long long)LN_COLS + p;
@@ -136,8 +139,8 @@ __global__ __launch_bounds__(LN_THREADS) void chan_layernorm_bwd_kernel(const fl
         bsum += __shfl_xor(bsum, off, 64);
       }
       if (p == 0) {
-        pg[(long long)blockIdx.x * Cc + c] = a;
-        pb[(long long)blockIdx.x * Cc + c] = bsum;
+        pg[(long long)blockIdx.x * prow + c] = a;
+        pb[(long long)blockIdx.x * prow + c] = bsum;
       }
     }
   }
@@ -163,15 +166,18 @@ __global__ __launch_bounds__(LN_THREADS) void chan_layernorm_bwd_kernel(const fl
       d[u] = dy[o];
       xv[u] = x[o];
     }
+    float av[LN_UNROLL];
+#pragma unroll
+    for (int u = 0; u < LN_UNROLL; ++u) av[u] = add ? add[(long long)(c + u * LN_GROUPS) * N + n] : 0.f;
 #pragma unroll
     for (int u = 0; u < LN_UNROLL; ++u) {
       const int cc = c + u * LN_GROUPS;
-      dx[(long long)cc * N + n] = r * (d[u] * g[cc] - m1) - k2 * (xv[u] - mean);
+      dx[(long long)cc * N + n] = r * (d[u] * g[cc] - m1) - k2 * (xv[u] - mean) + av[u];
     }
   }
   for (; c < Cc; c += LN_GROUPS) {
     const long long o = (long long)c * N + n;
-    dx[o] = r * (dy[o] * g[c] - m1) - k2 * (x[o] - mean);
+    dx[o] = r * (dy[o] * g[c] - m1) - k2 * (x[o] - mean) + (add ? add[o] : 0.f);
   }
 }
 
@@ -267,7 +273,10 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 __global__ __launch_bounds__(256) void bn_rows_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ y,
                                                           float* __restrict__ mean_out, float* __restrict__ var_out, long long N,
-                                                          float eps) {
+                                                          float eps, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                          float momentum) {
+  // run_mean / run_var (nullable, together): nn.BatchNorm1d's running statistics, updated in place as torch does
+  // (running = (1 - momentum) * running + momentum * batch; the variance with the unbiased N / (N - 1) factor)
   __shared__ float red[4];
   const int c = blockIdx.x;
   const float* xr = x + (long long)c * N;
@@ -283,14 +292,23 @@ __global__ __launch_bounds__(256) void bn_rows_fwd_kernel(const float* __restric
   const float sc = gamma[c] * rsqrtf(var + eps), sh = beta[c] - mean * sc;
   float* yr = y + (long long)c * N;
   for (long long i = threadIdx.x; i < N; i += 256) yr[i] = xr[i] * sc + sh;
-  if (threadIdx.x == 0) { mean_out[c] = mean; var_out[c] = var; }
+  if (threadIdx.x == 0) {
+    mean_out[c] = mean;
+    var_out[c] = var;
+    if (run_mean != nullptr) {
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * (var * ((float)N / (float)(N > 1 ? N - 1 : 1)));
+    }
+  }
 }
 
 // dx = gamma * rstd * (dy - mean(dy) - xhat * mean(dy * xhat)),  dgamma = sum dy * xhat,  dbeta = sum dy
 __global__ __launch_bounds__(256) void bn_rows_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                                           const float* __restrict__ var, float* __restrict__ dx,
-                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, long long N, float eps) {
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, long long N, float eps,
+                                                          const float* __restrict__ add) {
+  // `add` (nullable, dx's shape): dx = BatchNorm backward + add (the skip connection's gradient, as in chan_layernorm_bwd)
   __shared__ float red[4];
   const int c = blockIdx.x;
   const float* xr = x + (long long)c * N;
@@ -306,7 +324,8 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_kernel(const float* __restric
   const float sum_dyx = block_sum_256(s2, red);
   const float k = gamma[c] * rstd, m1 = sum_dy / (float)N, m2 = sum_dyx / (float)N;
   float* o = dx + (long long)c * N;
-  for (long long i = threadIdx.x; i < N; i += 256) o[i] = k * (dr[i] - m1 - (xr[i] - mu) * rstd * m2);
+  const float* ar = add ? add + (long long)c * N : nullptr;
+  for (long long i = threadIdx.x; i < N; i += 256) o[i] = k * (dr[i] - m1 - (xr[i] - mu) * rstd * m2) + (ar ? ar[i] : 0.f);
   if (threadIdx.x == 0) { dgamma[c] = sum_dyx; dbeta[c] = sum_dy; }
 }
 
@@ -317,16 +336,36 @@ using namespace advhip;
 extern "C" int advhip_bn_rows_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* var,
                                       int32_t C, int64_t N, float eps, void* stream) {
   ADVHIP_REQUIRE(x && gamma && beta && y && mean && var && C > 0 && N > 0, "bn_rows_fwd: bad arguments");
-  hipLaunchKernelGGL(bn_rows_fwd_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, var, (long long)N, eps);
+  hipLaunchKernelGGL(bn_rows_fwd_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, var, (long long)N, eps,
+                     (float*)nullptr, (float*)nullptr, 0.f);
   return check_launch("bn_rows_fwd");
+}
+
+extern "C" int advhip_bn_rows_fwd_running_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* var,
+                                              float* running_mean, float* running_var, float momentum, int32_t C, int64_t N, float eps,
+                                              void* stream) {
+  ADVHIP_REQUIRE(x && gamma && beta && y && mean && var && C > 0 && N > 0, "bn_rows_fwd_running: bad arguments");
+  ADVHIP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_rows_fwd_running: running_mean and running_var come together");
+  hipLaunchKernelGGL(bn_rows_fwd_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, var, (long long)N, eps,
+                     running_mean, running_var, momentum);
+  return check_launch("bn_rows_fwd_running");
 }
 
 extern "C" int advhip_bn_rows_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* var,
                                       float* dx, float* dgamma, float* dbeta, int32_t C, int64_t N, float eps, void* stream) {
   ADVHIP_REQUIRE(dy && x && gamma && mean && var && dx && dgamma && dbeta && C > 0 && N > 0, "bn_rows_bwd: bad arguments");
   hipLaunchKernelGGL(bn_rows_bwd_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, var, dx, dgamma, dbeta,
-                     (long long)N, eps);
+                     (long long)N, eps, (const float*)nullptr);
   return check_launch("bn_rows_bwd");
+}
+
+extern "C" int advhip_bn_rows_bwd_add_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* var,
+                                          const float* add, float* dx, float* dgamma, float* dbeta, int32_t C, int64_t N, float eps,
+                                          void* stream) {
+  ADVHIP_REQUIRE(dy && x && gamma && mean && var && dx && dgamma && dbeta && C > 0 && N > 0, "bn_rows_bwd_add: bad arguments");
+  hipLaunchKernelGGL(bn_rows_bwd_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, var, dx, dgamma, dbeta,
+                     (long long)N, eps, add);
+  return check_launch("bn_rows_bwd_add");
 }
 
 extern "C" int advhip_chan_stats_f32(const float* x, float* mu, float* rs, int32_t C, int64_t N, float eps, void* stream) {
@@ -356,8 +395,19 @@ extern "C" int advhip_chan_layernorm_bwd_f32(const float* dy, const float* x, co
   const long long blocks = (N + LN_COLS - 1) / LN_COLS;
   ADVHIP_REQUIRE(blocks < (1ll << 31), "chan_layernorm_bwd: too many positions");
   hipLaunchKernelGGL(chan_layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, dy, x, g, mu, rs, dx,
-                     dg_partial, db_partial, C, (long long)N, eps);
+                     dg_partial, db_partial, C, (long long)N, eps, (const float*)nullptr, (long long)C);
   return check_launch("chan_layernorm_bwd");
+}
+
+extern "C" int advhip_chan_layernorm_bwd_add_f32(const float* dy, const float* x, const float* g, const float* mu, const float* rs,
+                                                 const float* add, float* dx, float* dgb_partial, int32_t C, int64_t N, float eps,
+                                                 void* stream) {
+  ADVHIP_REQUIRE(dy && x && g && mu && rs && dx && dgb_partial && C > 0 && N > 0, "chan_layernorm_bwd_add: bad arguments");
+  const long long blocks = (N + LN_COLS - 1) / LN_COLS;
+  ADVHIP_REQUIRE(blocks < (1ll << 31), "chan_layernorm_bwd_add: too many positions");
+  hipLaunchKernelGGL(chan_layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, dy, x, g, mu, rs, dx,
+                     dgb_partial, dgb_partial + C, C, (long long)N, eps, add, 2ll * C);
+  return check_launch("chan_layernorm_bwd_add");
 }
 
 extern "C" int advhip_unfold3_f32(const float* x, float* u, int32_t C, int64_t rows, int32_t T, void* stream) {

@@ -37,7 +37,7 @@ _CONST: Dict[Tuple, torch.Tensor] = {}
 # token conv: 2.49 vs 2.84 ms per video); with autograd they stay on torch (their weight-gradient GEMMs are tiny and the
 # k = 3 unfold of the 2048-channel input costs more than it saves: 22.5 vs 22.0 ms per training step)
 MIN_CHANNELS_INFER = int(os.environ.get("ADV_MGFN_HIP_MIN_CHANNELS", "64"))
-MIN_CHANNELS_TRAIN = 128
+MIN_CHANNELS_TRAIN = int(os.environ.get("ADV_MGFN_HIP_MIN_CHANNELS_TRAIN", "128"))
 
 
 def _on_current_device(x: torch.Tensor) -> bool:
@@ -134,6 +134,16 @@ def pack_kc(w: torch.Tensor) -> torch.Tensor:
     wp = torch.empty((lib.advhip_conv3d_packed_rows(C.byref(d)), cout), device=w.device, dtype=torch.float32)
     _lib.require_gpu(w, contiguous=False)
     check(lib.advhip_conv3d_pack_weight_f32(C.byref(d), ptr(w.contiguous()), ptr(wp), stream(w)), "pack_weight")
+    return wp
+
+
+def pack_dx(w: torch.Tensor) -> torch.Tensor:
+    """(Cout, Cin, k) Conv1d weights -> the packed operand [Cout*k (padded to 32)][Cin] of the transposed conv that computes
+    the layer's input gradient (include/advhip.h: advhip_conv1d_pack_weight_dx_f32)."""
+    cout, cin, k = w.shape
+    _lib.require_gpu(w)
+    wp = torch.empty((-(-(cout * k) // 32) * 32, cin), device=w.device, dtype=torch.float32)
+    check(_lib.load().advhip_conv1d_pack_weight_dx_f32(ptr(w), ptr(wp), cout, cin, k, stream(w)), "pack_weight_dx")
     return wp
 
 
@@ -287,16 +297,16 @@ class _LinearCN(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if k == 1:  # dX = W^T dY: the parameter's own (o, c) layout IS the kernels' [K = o][Cout = c] operand
                 dx = conv_cn(dy, weight.detach().view(cout, cin), cin, 1, residual=dy if fold else None)
-            else:       # transposed conv: W'[c][o][j] = W[o][c][k-1-j]
-                dx = conv_cn(dy, pack_kc(weight.detach().flip(2).transpose(0, 1)), cin, k, residual=dy if fold else None)
+            else:       # transposed conv: W'[c][o][j] = W[o][c][k-1-j], packed straight from the parameter (one launch)
+                dx = conv_cn(dy, pack_dx(weight.detach()), cin, k, residual=dy if fold else None)
         with _Fork(dy, x) as fk:
-            if ctx.needs_input_grad[1]:
-                dy2 = dy.view(cout, -1)
-                if k == 1:
-                    dw = ops.gemm_nt(dy2, x.detach().view(cin, -1)).view(cout, cin, 1)
-                else:
-                    dw = ops.gemm_nt(dy2, _unfold3(x.detach())).view(cout, cin, 3)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
+            want_db = ctx.has_bias and ctx.needs_input_grad[2]
+            if ctx.needs_input_grad[1]:  # dW = dY X^T, and db = rowsum(dY) out of the same launch
+                xk = x.detach().view(cin, -1) if k == 1 else _unfold3(x.detach())
+                res = ops.gemm_nt(dy.view(cout, -1), xk, rowsum=want_db)
+                dw, db = res if want_db else (res, None)
+                dw = dw.view(cout, cin, k)
+            elif want_db:
                 db = dy.sum(dim=(1, 2))
             fk.out(dw, db)
         return dx, dw, db, (None if fold else (dy if ctx.has_res and ctx.needs_input_grad[3] else None)), None
@@ -323,17 +333,149 @@ class _FFNCN(torch.autograd.Function):
         xh, z, h, w1, w2 = ctx.saved_tensors
         hid, dim = w1.shape[0], w1.shape[1]
         dy = dy.contiguous()
+        def dw_db(g, act, want_w, want_b):  # dW = g act^T (+ db = rowsum(g) out of the same launch)
+            if want_w:
+                res = ops.gemm_nt(g.view(g.shape[0], -1), act.view(act.shape[0], -1), rowsum=want_b)
+                w, b = res if want_b else (res, None)
+                return w.view(g.shape[0], act.shape[0], 1), b
+            return None, (g.sum(dim=(1, 2)) if want_b else None)
+
         with _Fork(dy, h) as fk:
-            dw2 = ops.gemm_nt(dy.view(dim, -1), h.view(hid, -1)).view(dim, hid, 1) if ctx.needs_input_grad[4] else None
-            db2 = dy.sum(dim=(1, 2)) if ctx.needs_input_grad[5] else None
+            dw2, db2 = dw_db(dy, h, ctx.needs_input_grad[4], ctx.needs_input_grad[5])
             fk.out(dw2, db2)
         dz = conv_cn(dy, w2.detach().view(dim, hid), hid, 1, dact_z=z)          # (W2^T dY) * GELU'(z)
         with _Fork(dz, xh) as fk:
-            dw1 = ops.gemm_nt(dz.view(hid, -1), xh.detach().view(dim, -1)).view(hid, dim, 1) if ctx.needs_input_grad[2] else None
-            db1 = dz.sum(dim=(1, 2)) if ctx.needs_input_grad[3] else None
+            dw1, db1 = dw_db(dz, xh.detach(), ctx.needs_input_grad[2], ctx.needs_input_grad[3])
             fk.out(dw1, db1)
         dxh = conv_cn(dz, w1.detach().view(hid, dim), dim, 1) if ctx.needs_input_grad[0] else None
         return dxh, (dy if ctx.needs_input_grad[1] else None), dw1, db1, dw2, db2, None
+
+
+def _dw_db(g: torch.Tensor, act: torch.Tensor, want_w: bool, want_b: bool):
+    """dW = g act^T over the positions (1x1 layer), and db = rowsum(g) out of the same launch."""
+    if want_w:
+        res = ops.gemm_nt(g.view(g.shape[0], -1), act.view(act.shape[0], -1), rowsum=want_b)
+        w, b = res if want_b else (res, None)
+        return w.view(g.shape[0], act.shape[0], 1), b
+    return None, (g.sum(dim=(1, 2)) if want_b else None)
+
+
+class _FFNBlockCN(torch.autograd.Function):
+    """y = x + W2 GELU(W1 LN(x) + b1) + b2: a whole `x = ffn(x) + x` step of a block (MGFNFeedForward + the residual add,
+    modeling_mgfn.py:49-64, 147, 205) as three launches forward (LayerNorm; GEMM + GELU; GEMM + bias + residual) and, backward,
+    two GEMM pairs (dW + db in one launch each, dX with GELU' in its epilogue) and ONE LayerNorm-backward launch that also adds
+    the skip connection's gradient and writes dg / db partial sums as one matrix."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, eps, w1, b1, w2, b2, fresh):
+        _lib.require_gpu(x, g, b, w1, b1, w2, b2, contiguous=False)
+        c = x.shape[0]
+        n = x.numel() // c
+        hid = w1.shape[0]
+        xh = torch.empty_like(x)
+        mu = torch.empty((n,), device=x.device, dtype=torch.float32)
+        rs = torch.empty_like(mu)
+        gf, bf = g.detach().reshape(c).contiguous(), b.detach().reshape(c).contiguous()
+        check(_lib.load().advhip_chan_layernorm_fwd_f32(ptr(x), ptr(gf), ptr(bf), ptr(xh), ptr(mu), ptr(rs), c, n, C.c_float(eps), stream(x)),
+              "chan_layernorm_fwd")
+        h, z = conv_cn(xh, pack_kc_cached(w1, fresh), hid, 1, shift=b1.detach(), act=ACT_GELU, want_preact=True)
+        y = conv_cn(h, pack_kc_cached(w2, fresh), c, 1, shift=b2.detach(), residual=x)
+        ctx.save_for_backward(x, gf, mu, rs, xh, z, h, w1, w2)
+        ctx.eps, ctx.gshape = eps, g.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gf, mu, rs, xh, z, h, w1, w2 = ctx.saved_tensors
+        hid, dim = w1.shape[0], w1.shape[1]
+        n = x.numel() // dim
+        need = ctx.needs_input_grad
+        dy = dy.contiguous()
+        dw2, db2 = _dw_db(dy, h, need[6], need[7])
+        dz = conv_cn(dy, w2.detach().view(dim, hid), hid, 1, dact_z=z)          # (W2^T dY) * GELU'(z)
+        dw1, db1 = _dw_db(dz, xh, need[4], need[5])
+        dxh = conv_cn(dz, w1.detach().view(hid, dim), dim, 1)
+        lib = _lib.load()
+        rows = lib.advhip_chan_layernorm_bwd_partial_rows(n)
+        dx = torch.empty_like(x)
+        pgb = torch.empty((rows, 2 * dim), device=x.device, dtype=torch.float32)
+        check(lib.advhip_chan_layernorm_bwd_add_f32(ptr(dxh), ptr(x), ptr(gf), ptr(mu), ptr(rs), ptr(dy), ptr(dx), ptr(pgb), dim, n,
+                                                    C.c_float(ctx.eps), stream(x)), "chan_layernorm_bwd_add")
+        sums = pgb.sum(0)
+        return dx, sums[:dim].reshape(ctx.gshape), sums[dim:].reshape(ctx.gshape), None, dw1, db1, dw2, db2, None
+
+
+class _FocusAttnBlockCN(torch.autograd.Function):
+    """y = x + to_out(rel_pos(to_v(BN(x)))): a whole `x = attention(x) + x` step of a FocusBlock (modeling_mgfn.py:150-180, 203)
+    in training mode: BatchNorm with batch statistics (running statistics updated inside the launch), GEMM, depth-wise
+    temporal conv, GEMM + bias + residual; backward with dW + db per launch and the skip connection's gradient added inside
+    the BatchNorm-backward launch."""
+
+    @staticmethod
+    def forward(ctx, x, bn_w, bn_b, wv, wrel, brel, wo, bo, bn, heads, fresh):
+        _lib.require_gpu(x, bn_w, bn_b, wv, wrel, brel, wo, bo, contiguous=False)
+        c, b_, t = x.shape
+        n = b_ * t
+        inner = wv.shape[0]
+        lib = _lib.load()
+        xb = torch.empty_like(x)
+        mean = torch.empty((c,), device=x.device, dtype=torch.float32)
+        var = torch.empty_like(mean)
+        track = bn.track_running_stats and bn.running_mean is not None
+        check(lib.advhip_bn_rows_fwd_running_f32(ptr(x), ptr(bn_w.detach()), ptr(bn_b.detach()), ptr(xb), ptr(mean), ptr(var),
+                                                 ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                                                 C.c_float(bn.momentum if track else 0.0), c, n, C.c_float(bn.eps), stream(x)), "bn_rows_fwd_running")
+        if track:
+            bn.num_batches_tracked += 1
+        v = conv_cn(xb, pack_kc_cached(wv, fresh), inner, 1)
+        k = wrel.shape[-1]
+        w2 = wrel.detach().reshape(heads, k).contiguous()
+        o = torch.empty_like(v)
+        check(lib.advhip_dwconv_t_fwd_f32(ptr(v), ptr(w2), ptr(brel.detach().contiguous()), ptr(o), inner, heads, b_, t, k, stream(x)), "dwconv_t_fwd")
+        y = conv_cn(o, pack_kc_cached(wo, fresh), c, 1, shift=bo.detach(), residual=x)
+        ctx.save_for_backward(x, bn_w, mean, var, xb, v, w2, o, wv, wo)
+        ctx.eps, ctx.heads, ctx.wrel_shape = bn.eps, heads, wrel.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, bn_w, mean, var, xb, v, w2, o, wv, wo = ctx.saved_tensors
+        c, b_, t = x.shape
+        inner, heads = wv.shape[0], ctx.heads
+        k = w2.shape[1]
+        need = ctx.needs_input_grad
+        lib = _lib.load()
+        dy = dy.contiguous()
+        dwo, dbo = _dw_db(dy, o, need[6], need[7])
+        do = conv_cn(dy, wo.detach().view(c, inner), inner, 1)
+        chunks = lib.advhip_dwconv_t_bwd_chunks(inner, b_)
+        dv = torch.empty_like(v)
+        partial = torch.empty((inner * chunks, k + 1), device=x.device, dtype=torch.float32)
+        check(lib.advhip_dwconv_t_bwd_f32(ptr(do), ptr(v), ptr(w2), ptr(dv), ptr(partial), inner, heads, b_, t, k, stream(x)), "dwconv_t_bwd")
+        per_head = partial.view(inner // heads, heads, chunks, k + 1).sum(dim=(0, 2))  # channel = c_idx * H + h_idx
+        dwv, _ = _dw_db(dv, xb, need[3], False)
+        dxb = conv_cn(dv, wv.detach().view(inner, c), c, 1)
+        dx = torch.empty_like(x)
+        dg = torch.empty((c,), device=x.device, dtype=torch.float32)
+        db = torch.empty_like(dg)
+        check(lib.advhip_bn_rows_bwd_add_f32(ptr(dxb), ptr(x), ptr(bn_w.detach()), ptr(mean), ptr(var), ptr(dy), ptr(dx), ptr(dg), ptr(db), c,
+                                             b_ * t, C.c_float(ctx.eps), stream(x)), "bn_rows_bwd_add")
+        return dx, dg, db, dwv, per_head[:, :k].reshape(ctx.wrel_shape), per_head[:, k].contiguous(), dwo, dbo, None, None, None
+
+
+def ffn_block_cn(x: torch.Tensor, norm, in_conv: torch.nn.Conv1d, out_conv: torch.nn.Conv1d) -> torch.Tensor:
+    """x + ffn(LN(x)) with autograd (the whole step as one Function: fewer launches, no separate skip-gradient add)."""
+    fresh = _will_train(in_conv.weight, in_conv.bias, out_conv.weight, out_conv.bias)
+    if fresh:
+        _FOLDED.pop(id(in_conv), None)
+    return _FFNBlockCN.apply(x.contiguous(), norm.g, norm.b, norm.eps, in_conv.weight, in_conv.bias, out_conv.weight, out_conv.bias, fresh)
+
+
+def focus_attention_block_cn(x: torch.Tensor, bn: torch.nn.BatchNorm1d, to_v, rel_pos, to_out, heads: int) -> torch.Tensor:
+    """x + to_out(rel_pos(to_v(BN_train(x)))) with autograd, as one Function."""
+    fresh = _will_train(to_v.weight, to_out.weight, to_out.bias)
+    return _FocusAttnBlockCN.apply(x.contiguous(), bn.weight, bn.bias, to_v.weight, rel_pos.weight, rel_pos.bias, to_out.weight, to_out.bias,
+                                   bn, heads, fresh)
 
 
 def _will_train(*params) -> bool:

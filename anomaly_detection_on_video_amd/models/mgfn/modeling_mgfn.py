@@ -150,6 +150,8 @@ class MGFNFeedForward(nn.Module):
             if not torch.is_grad_enabled():
                 if residual is x:
                     return mgfn_ops.ffn_cn_folded_ln(x, self.layer_norm, self.in_conv, self.out_conv)
+            elif residual is x and mgfn_ops.fused_ok(x) and self.in_conv.bias is not None and self.out_conv.bias is not None:
+                return mgfn_ops.ffn_block_cn(x, self.layer_norm, self.in_conv, self.out_conv)  # LN + FFN + skip: one autograd node
             return mgfn_ops.ffn_cn(self.layer_norm(x), residual, self.in_conv, self.out_conv)
         y = _pointwise(self.out_conv, self.dropout(self.gelu(_pointwise(self.in_conv, self.layer_norm(x)))))
         return y if residual is None else y + residual
@@ -169,7 +171,13 @@ class MGFNFeatureAmplifier(nn.Module):
     def forward(self, x):
         bs, ncrops, t, c = x.shape
         x = x.reshape(bs * ncrops, t, c).permute(2, 0, 1)  # (C+1, B, T) view
-        return _conv_k(self.to_tokens, x[: self.channels]) + self.mag_ratio * _conv_k(self.to_mag, x[self.channels :])
+        if torch.is_grad_enabled() and self.to_tokens.weight.requires_grad:
+            # with autograd the 2048 -> 64 token conv stays a torch GEMM: its weight gradient on the HIP path would unfold the
+            # 2048-channel input (252 MB) for a 64-row product
+            tokens = _conv_k_torch(self.to_tokens, x[: self.channels])
+        else:
+            tokens = _conv_k(self.to_tokens, x[: self.channels])
+        return tokens + self.mag_ratio * _conv_k(self.to_mag, x[self.channels :])
 
 
 class GlanceAttention(nn.Module):
@@ -232,6 +240,12 @@ class FocusAttention(nn.Module):
 
     def forward(self, x, residual: Optional[torch.Tensor] = None):  # (C, B, T)
         _, b, n = x.shape
+        bn = self.norm
+        if (residual is x and torch.is_grad_enabled() and bn.training and bn.momentum is not None and bn.affine
+                and mgfn_ops.fused_ok(x) and _hip(self.to_v, x) and _hip(self.to_out, x) and self.to_v.bias is None
+                and self.to_out.bias is not None and self.rel_pos.weight.shape[-1] in (3, 5)):
+            # BN + to_v + rel_pos + to_out + skip as one autograd node (mgfn_ops._FocusAttnBlockCN)
+            return mgfn_ops.focus_attention_block_cn(x, bn, self.to_v, self.rel_pos, self.to_out, self.heads)
         v = _pointwise(self.to_v, self._batch_norm(x))
         inner = v.shape[0]
         h = self.heads

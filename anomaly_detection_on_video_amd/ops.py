@@ -462,18 +462,40 @@ def softmax_rows(x: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor
     return y
 
 
-def gemm_nt(a: torch.Tensor, b: torch.Tensor, splits: int = 0) -> torch.Tensor:
+# (M, N) -> (tile id, K slices) of advhip_gemm_nt_rowsum_f32 at K = 10 240, measured on one MI355X (tools/tune_gemm_nt.py,
+# profiles/r03_gemm_nt_tune.txt): the weight-gradient shapes of the MGFN scorer at its training batch.  Other shapes: heuristic.
+GEMM_NT_TUNED: Dict[Tuple[int, int, int], Tuple[int, int]] = {
+    (4096, 1024, 10240): (3, 4), (1024, 4096, 10240): (3, 3), (1024, 1024, 10240): (3, 8), (1024, 3072, 10240): (3, 4),
+    (1024, 128, 10240): (1, 32), (512, 128, 10240): (1, 32), (128, 512, 10240): (1, 32),
+}
+
+
+def gemm_nt_choice(M: int, N: int, K: int) -> Tuple[int, int]:
+    hit = GEMM_NT_TUNED.get((M, N, K))
+    if hit is not None:
+        return hit
+    tiles = -(-M // 64) * -(-N // 64)
+    return 0, max(1, min(64, 1024 // max(tiles, 1), K // 256))  # few output tiles (128-channel layers): many K slices
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, splits: int = 0, rowsum: bool = False, tile: int = 0):
     """a (M, K) @ b (N, K)^T -> (M, N) for two k-contiguous operands (row pitch = stride(0)); K % 16 == 0.  The weight
-    gradient of a GEMM-shaped layer with (channel, position) activations (include/advhip.h: advhip_gemm_nt_f32).
-    `splits`: K slices (0 = enough to fill the chip); the slices are summed here."""
+    gradient of a GEMM-shaped layer with (channel, position) activations (include/advhip.h: advhip_gemm_nt_rowsum_f32).
+    `splits`: K slices (0 = the measured / heuristic choice); the slices are summed here.  `rowsum`: also return the row
+    sums of `a` (M,) -- the bias gradient of the same layer, out of the same launch."""
     require_gpu(a, b, contiguous=False)
     if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1] or a.stride(1) != 1 or b.stride(1) != 1:
         raise ValueError(f"gemm_nt: need (M,K) and (N,K) with unit inner stride, got {tuple(a.shape)} {a.stride()} / {tuple(b.shape)} {b.stride()}")
     M, K = a.shape
     N = b.shape[0]
     if splits <= 0:
-        tiles = -(-M // 64) * -(-N // 64)
-        splits = max(1, min(64, 1024 // max(tiles, 1), K // 256))  # few output tiles (128-channel layers): many K slices
+        t, splits = gemm_nt_choice(M, N, K)
+        tile = tile or t
     out = torch.empty((splits, M, N), device=a.device, dtype=torch.float32)
-    check(_lib.load().advhip_gemm_nt_f32(ptr(a), ptr(b), ptr(out), M, N, K, a.stride(0), b.stride(0), N, splits, M * N, stream()), "gemm_nt")
-    return out[0] if splits == 1 else out.sum(0)
+    rs = torch.empty((splits, M), device=a.device, dtype=torch.float32) if rowsum else None
+    check(_lib.load().advhip_gemm_nt_rowsum_f32(ptr(a), ptr(b), ptr(out), ptr(rs), M, N, K, a.stride(0), b.stride(0), N, splits, M * N, tile,
+                                                stream(a)), "gemm_nt")
+    out = out[0] if splits == 1 else out.sum(0)
+    if not rowsum:
+        return out
+    return out, (rs[0] if splits == 1 else rs.sum(0))

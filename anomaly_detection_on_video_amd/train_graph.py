@@ -12,8 +12,10 @@ inside allocates or synchronises outside torch's allocator) and replayed with th
     replay always packs the live parameters; `mgfn_ops.invalidate_caches()` runs after every replay for the inference
     caches, as after an eager optimizer step;
   * dropout masks of the MIL head come from torch's graph-safe Philox state: a different mask every replay;
-  * weight gradients and bias gradients run on a side stream inside the captured graph (mgfn_ops.overlapped_backward):
-    forked off the `dX` chain, joined before the optimizer -- the graph keeps that concurrency.
+  * `overlap=True` (opt-in) issues weight and bias gradients on a side stream inside the captured graph
+    (mgfn_ops.overlapped_backward: forked off the `dX` chain, joined before the optimizer).  Measured on one MI355X at
+    (32,10,32,2049): 19.3-19.4 ms against 18.6 ms serial -- two MFMA-bound GEMMs side by side run slower than one after the
+    other here (unlike the extraction stream, whose lanes pair MFMA-bound with memory-bound launches), so it stays off.
 
 Adam must be created with `capturable=True` (its step counters live on the device).
 """
@@ -32,7 +34,7 @@ class GraphedTrainStep:
     operand); the next call captures and replays; a call with other shapes falls back to the eager step."""
 
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, eager_steps: int = 3,
-                 clip_grad_norm: Optional[float] = None, overlap: bool = True,
+                 clip_grad_norm: Optional[float] = None, overlap: bool = False,
                  after_step: Optional[Callable[[], None]] = None):
         for g in optimizer.param_groups:
             if not g.get("capturable", False):

@@ -268,6 +268,14 @@ int advhip_bgemm_f32(const advhip_gemm_desc* d, const float* A, const float* B, 
 int advhip_gemm_nt_f32(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb,
                        int64_t ldc, int32_t splits, int64_t slab_stride, void* stream);
 
+/* The same product with the row sums of A beside it: rowsum_a[s][m] = sum over K slice s of A[m][k] (nullable) -- the bias
+ * gradient db[o] = sum_n dY[o][n] of the same layer (autograd of nn.Conv1d's bias, modeling_mgfn.py:53-56, 101, 155, 167) out of
+ * the fragments the n-tile-0 workgroups hold anyway, instead of a second pass over dY.  `tile`: 0 = heuristic, 1 = 64 x 64,
+ * 2 = 128 x 64, 3 = 128 x 128 output tile per workgroup. */
+int advhip_gemm_nt_rowsum_f32(const float* A, const float* B, float* C, float* rowsum_a, int32_t M, int32_t N, int32_t K,
+                              int64_t lda, int64_t ldb, int64_t ldc, int32_t splits, int64_t slab_stride, int32_t tile,
+                              void* stream);
+
 /* y[r, :] = softmax(x[r, :] * scale) over rows of n contiguous floats (F.softmax(theta_phi * dim_inner**-0.5, dim=-1),
  * src/i3d.py:174-175; the attention softmax of GlanceAttention, modeling_mgfn.py:115-120).  x == y allowed. */
 int advhip_softmax_rows_f32(const float* x, float* y, int64_t rows, int32_t n, float scale, void* stream);
@@ -290,6 +298,26 @@ int advhip_bn_rows_fwd_f32(const float* x, const float* gamma, const float* beta
                            int64_t N, float eps, void* stream);
 int advhip_bn_rows_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* var, float* dx,
                            float* dgamma, float* dbeta, int32_t C, int64_t N, float eps, void* stream);
+
+/* The same three with the fusions a training step's launch count asks for (bit-identical arithmetic):
+ *   advhip_bn_rows_fwd_running_f32: also updates nn.BatchNorm1d's running_mean / running_var in place (nullable, together:
+ *     running = (1 - momentum) * running + momentum * batch, the variance unbiased) -- torch's five small launches;
+ *   advhip_bn_rows_bwd_add_f32 / advhip_chan_layernorm_bwd_add_f32: dx = backward + add (nullable, dx's shape) -- the
+ *     gradient of the block's skip connection (y = f(norm(x)) + x) without autograd's separate add; the LayerNorm form writes
+ *     its per-block partial sums as ONE [rows][2C] matrix (dg in columns [0, C), db in [C, 2C)): one reduction for both. */
+int advhip_bn_rows_fwd_running_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* var,
+                                   float* running_mean, float* running_var, float momentum, int32_t C, int64_t N, float eps,
+                                   void* stream);
+int advhip_bn_rows_bwd_add_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* var,
+                               const float* add, float* dx, float* dgamma, float* dbeta, int32_t C, int64_t N, float eps, void* stream);
+int advhip_chan_layernorm_bwd_add_f32(const float* dy, const float* x, const float* g, const float* mu, const float* rs,
+                                      const float* add, float* dx, float* dgb_partial, int32_t C, int64_t N, float eps, void* stream);
+
+/* The packed operand of a Conv1d's transposed conv (its input gradient dX = conv1d(dY; W'), W'[c][o][j] = W[o][c][k-1-j];
+ * autograd of nn.Conv1d, modeling_mgfn.py:101,155) straight from the parameter w (Cout, Cin, k):
+ * w_packed[(o*k + j)][c] = w[o][c][k-1-j], rows padded with zeros to a multiple of 32 -- one launch instead of flip +
+ * transpose + pack. */
+int advhip_conv1d_pack_weight_dx_f32(const float* w, float* w_packed, int32_t Cout, int32_t Cin, int32_t k, void* stream);
 
 /* The operand of a k = 3, padding 1 Conv1d's weight gradient (autograd of nn.Conv1d, modeling_mgfn.py:101,155):
  * u[(c*3 + j), r, t] = x[c, r, t + j - 1] (zero outside [0, T)), x (C, rows, T) -> u (3C, rows, T); dW = dY . u^T by

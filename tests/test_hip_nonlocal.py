@@ -205,6 +205,25 @@ def test_gemm_nt_vs_torch_fp64(M, N, K, splits):
     assert torch.equal(out, ops.gemm_nt(a, b, splits))
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K,splits", [(64, 64, 16, 1), (100, 70, 160, 1), (256, 192, 1024, 4), (1024, 384, 10240, 2), (130, 1024, 2048, 3), (1, 5, 32, 2)])
+def test_gemm_nt_row_sums_and_tiles_vs_torch_fp64(M, N, K, splits, tile):
+    """advhip_gemm_nt_rowsum_f32: every output tile size, with the row sums of A (the bias gradient beside dW = dY X^T) taken
+    from the fragments of the n-tile-0 workgroups: both against fp64, ragged shapes, K slices; run-to-run bit-identical."""
+    from anomaly_detection_on_video_amd import ops
+
+    a = synth_tensor(f"ntr.a{M}{K}", (M, K + 32), scale=1.0).to(_dev())[:, 16 : 16 + K]
+    b = synth_tensor(f"ntr.b{N}{K}", (N, K), scale=1.0).to(_dev())
+    out, rs = ops.gemm_nt(a, b, splits, rowsum=True, tile=tile)
+    assert out.shape == (M, N) and rs.shape == (M,)
+    assert rel_err(out.cpu(), a.double().cpu() @ b.double().cpu().t()) < 3e-6
+    want = a.double().cpu().sum(1)
+    assert float((rs.cpu().double() - want).abs().max()) < 3e-6 * float(a.double().abs().sum(1).max())
+    out2, rs2 = ops.gemm_nt(a, b, splits, rowsum=True, tile=tile)
+    assert torch.equal(out, out2) and torch.equal(rs, rs2)
+    assert torch.equal(out, ops.gemm_nt(a, b, splits, tile=tile))  # the product does not depend on the row sums being taken
+
+
 def test_long_video_segment_cache_and_resume(tmp_path):
     """extract_features.py:116-148: long videos are extracted per segment of frames, each segment cached as
     <out>/<name>/<name>_<seg>.npy and re-used when the run is repeated; the stacked result equals the un-segmented one."""
