@@ -112,6 +112,10 @@ SIGNATURES = {
     "advhip_bgemm_f32": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P]),
     "advhip_gemm_nt_f32": (C.c_int, [_P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _L, _P]),
     "advhip_gemm_nt_rowsum_f32": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _L, _I, _P]),
+    "advhip_gemm_nt_workspace_bytes": (_L, [_I, _I, _I, _I]),
+    "advhip_gemm_nt_reduced_f32": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _I, _P, _L, _P]),
+    "advhip_gemm_nt_slabs_f32": (C.c_int, [_P, _P, _P, _I, _I, _I, _L, _L, _I, _I, _I, _P]),
+    "advhip_sum_slabs_f32": (C.c_int, [_P, _P, _L, _I, _L, _P]),
     "advhip_softmax_rows_f32": (C.c_int, [_P, _P, _L, _I, C.c_float, _P]),
     "advhip_conv3d_bn_act_ex_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _L, _P, _P, _P, _P, _P, _P, _L, C.POINTER(ConvEpilogue), _P, _L, _P]),
     "advhip_chan_stats_f32": (C.c_int, [_P, _P, _P, _I, _L, C.c_float, _P]),

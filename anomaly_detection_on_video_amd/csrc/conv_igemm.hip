@@ -1463,11 +1463,22 @@ struct GemmKKArgs {
   int tiles_m, tiles_n, splits;
   long long slab;       // elements between the outputs of consecutive K slices
   float* rowsum;        // nullable [splits][M]: sum over the K slice of A[m][k] (the bias gradient beside dW = dY X^T)
+  long long rs_slab;    // elements between the row sums of consecutive K slices (M when they are a matrix of their own)
+  // in-kernel reduction of the K slices (nullable): every (tile, slice) workgroup publishes its partial tile (and row sums),
+  // draws a ticket on the tile's arrival counter, and the last arriver sums the slices in slice order and writes C / rowsum
+  // (slab 0).  Counters are zero on entry and are left zero (the last arriver resets its tile's counter).
+  float* part;          // [tiles][splits][BM*BN] fragment-major, then [tiles_m][splits][BM] row-sum partials
+  unsigned* cnt;        // [tiles]
+  unsigned part_bytes;
 };
 
-template <int BM, int BN>
+// NS: ring depth.  2 (one k-tile in flight) where several workgroups per CU cover each other's LDS-DMA latency; deeper for
+// grids of one or two workgroups per CU (the small layers' weight gradients: few output tiles, K = 10 240), which otherwise
+// pay a memory round trip per k-tile.
+template <int BM, int BN, int NS = 2>
 __global__ __launch_bounds__(256) void gemm_kk_dma_kernel(const GemmKKArgs g) {
   constexpr int BK = 16, FM = BM / 32, FN = BN / 32;
+  static_assert(NS >= 2 && NS <= 8, "ring depth");
   constexpr int STAGE = (BM + BN) * BK;  // floats
   constexpr int LA = BM * 4 / 256, LB = BN * 4 / 256;  // 16-byte LDS-DMA instructions per wave per k-tile
   static_assert(LA >= 1 && LB >= 1, "tile too small");
@@ -1478,7 +1489,7 @@ __global__ __launch_bounds__(256) void gemm_kk_dma_kernel(const GemmKKArgs g) {
 #else
   constexpr int DMA_BYTES = 4;
 #endif
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) float smem[NS * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1534,12 +1545,22 @@ __global__ __launch_bounds__(256) void gemm_kk_dma_kernel(const GemmKKArgs g) {
 
   const int nk_all = g.K / BK;
   const int kt0 = (nk_all * split) / g.splits, kt1 = (nk_all * (split + 1)) / g.splits;
-  if (kt0 < kt1) issue(kt0, 0);
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i)
+    if (kt0 + i < kt1) issue(kt0 + i, i);
   int stage = 0;
   for (int kt = kt0; kt < kt1; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");  // tile kt is in LDS for every wave; the other stage is free
-    if (kt + 1 < kt1) issue(kt + 1, stage ^ 1);
+    // tile kt has landed once only the loads of the younger tiles in flight (<= NS - 2) are outstanding
+    if constexpr (NS == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      const int younger = kt1 - 1 - kt < NS - 2 ? kt1 - 1 - kt : NS - 2;
+      [&]<int... Y>(std::integer_sequence<int, Y...>) {
+        ((younger == Y ? (void)({ asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Y * (LA + LB)) : "memory"); }) : (void)0), ...);
+      }(std::make_integer_sequence<int, NS - 1>{});
+    }
+    asm volatile("s_barrier" ::: "memory");  // tile kt is in LDS for every wave; the stage read in the previous iteration is free
+    if (kt + NS - 1 < kt1) issue(kt + NS - 1, stage == 0 ? NS - 1 : stage - 1);
     __builtin_amdgcn_sched_barrier(0);
     const unsigned aa = a_addr0 + (unsigned)(stage * STAGE * 4), ba = b_addr0 + (unsigned)(stage * STAGE * 4);
     Frag<4> fa[FM], fb[FN];
@@ -1562,20 +1583,95 @@ __global__ __launch_bounds__(256) void gemm_kk_dma_kernel(const GemmKKArgs g) {
       for (int i = 0; i < FM; ++i) rs[i] += (fa[i].v[0] + fa[i].v[1]) + (fa[i].v[2] + fa[i].v[3]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    stage ^= 1;
+    stage = stage == NS - 1 ? 0 : stage + 1;
   }
   if (do_rs) {
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      float v = rs[i];
-      v += __shfl_xor(v, 16);
-      v += __shfl_xor(v, 32);
+      rs[i] += __shfl_xor(rs[i], 16);
+      rs[i] += __shfl_xor(rs[i], 32);
+    }
+  }
+  int out_split = split;
+  if (g.part != nullptr && g.splits > 1) {
+    // ---- in-kernel reduction of the K slices (the conv kernel's write-through form: cdna_hip_programming.md section 5)
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    const auto rp = __builtin_amdgcn_make_buffer_rsrc(g.part, 0, g.part_bytes, 0x00020000);
+    constexpr unsigned TILE_BYTES = BM * BN * 4;
+    const unsigned my = (unsigned)(L * g.splits + split) * TILE_BYTES + (unsigned)tid * 16u;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rp, my + (unsigned)(i * FN + j) * 4096u, 0, 16);
+    const unsigned rs_base = (unsigned)ntiles * (unsigned)g.splits * TILE_BYTES + (unsigned)(tile_m * g.splits) * (unsigned)(BM * 4);
+    if (do_rs && lg == 0) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rs[i]), rp,
+                                              rs_base + (unsigned)(split * BM + wm * (BM / 2) + 16 * i + li) * 4u, 0, 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores ...
+    __syncthreads();                                   // ... before one lane signals for all of them
+    unsigned* flag = reinterpret_cast<unsigned*>(smem);
+    if (tid == 0) *flag = __hip_atomic_fetch_add(g.cnt + L, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool last = *flag == (unsigned)(g.splits - 1);
+    if (!last) return;
+    if (tid == 0) __hip_atomic_store(g.cnt + L, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every slice has arrived: ready for the next launch
+    const unsigned t0 = (unsigned)(L * g.splits) * TILE_BYTES + (unsigned)tid * 16u;
+    // G float4 of SU slices are loaded before any is added (the adds stay in slice order: deterministic): the last arriver's
+    // sum is a chain of dependent round trips otherwise -- 40 of them for a small output cut into 40 slices
+    constexpr int NV = FM * FN, G = NV < 4 ? NV : 4, SU = NV >= 16 ? 2 : 4;
+    auto at = [&](int v) -> f32x4& { return acc[v / FN][v % FN]; };
+#pragma unroll
+    for (int g0 = 0; g0 < NV; g0 += G) {
+#pragma unroll
+      for (int v = 0; v < G; ++v)
+        at(g0 + v) = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, t0 + (unsigned)(g0 + v) * 4096u, 0, 16));
+#pragma unroll 1
+      for (int sl = 1; sl < g.splits; sl += SU) {
+        f32x4 t[SU][G];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          // (slices past the end: re-read the last one and add zero times it -- keeps the loop body branch-free)
+          const int ss = sl + u < g.splits ? sl + u : g.splits - 1;
+          const unsigned ts = t0 + (unsigned)ss * TILE_BYTES;
+#pragma unroll
+          for (int v = 0; v < G; ++v)
+            t[u][v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, ts + (unsigned)(g0 + v) * 4096u, 0, 16));
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          if (sl + u < g.splits) {
+#pragma unroll
+            for (int v = 0; v < G; ++v) at(g0 + v) += t[u][v];
+          }
+        }
+      }
+    }
+    if (do_rs && lg == 0) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const unsigned o = rs_base + (unsigned)(wm * (BM / 2) + 16 * i + li) * 4u;
+        float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, o, 0, 16));
+#pragma unroll 1
+        for (int sl = 1; sl < g.splits; ++sl)
+          v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, o + (unsigned)(sl * BM) * 4u, 0, 16));
+        rs[i] = v;
+      }
+    }
+    out_split = 0;
+  }
+  if (do_rs && lg == 0) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
       const int m = m0 + wm * (BM / 2) + 16 * i + li;
-      if (lg == 0 && m < g.M) g.rowsum[(long long)split * g.M + m] = v;
+      if (m < g.M) g.rowsum[(long long)out_split * g.rs_slab + m] = rs[i];
     }
   }
   // D[row = 4 lg + r][col = li] of fragment (i, j): m = m0 + wm*BM/2 + 16 i + 4 lg + r, n = n0 + wn*BN/2 + 16 j + li
-  float* __restrict__ C = g.C + (long long)split * g.slab;
+  float* __restrict__ C = g.C + (long long)out_split * g.slab;
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -2667,30 +2763,56 @@ extern "C" int advhip_conv3d_bn_act_maxpool211_f32(const advhip_conv3d_desc* d, 
 
 // ---- "NT" product of two k-contiguous operands (weight gradients of the GEMM-shaped MGFN layers) --------------------------
 namespace advhip {
+constexpr long long GEMM_NT_CNT_BYTES = 65536;  // arrival counters: the first 64 KiB of the workspace, whatever the shape
+
+static void gemm_nt_tile(int32_t M, int32_t N, int32_t splits, int32_t& tile, int& bm, int& bn) {
+  if (tile == 0) tile = ((long long)((M + 127) / 128) * ((N + 63) / 64) * splits >= 1536) ? 2 : 1;
+  bm = tile == 1 ? 64 : 128;
+  bn = tile == 3 ? 128 : 64;
+}
+
 static int gemm_nt_launch(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb,
-                          int64_t ldc, int32_t splits, int64_t slab_stride, int32_t tile, float* rowsum_a, void* stream) {
+                          int64_t ldc, int32_t splits, int64_t slab_stride, int32_t tile, float* rowsum_a, void* workspace,
+                          int64_t workspace_bytes, void* stream, int64_t rowsum_slab_stride = 0) {
   ADVHIP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "gemm_nt: bad arguments");
   ADVHIP_REQUIRE(K % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0,
                  "gemm_nt: K=%d must be a multiple of 16 and the operands 16-byte aligned with row pitches that are multiples of 4", K);
   ADVHIP_REQUIRE(lda >= K && ldb >= K && ldc >= N, "gemm_nt: row pitch smaller than a row");
   const long long a_bytes = ((long long)(M - 1) * lda + K) * 4, b_bytes = ((long long)(N - 1) * ldb + K) * 4;
   ADVHIP_REQUIRE(a_bytes < 0xF0000000ll && b_bytes < 0xF0000000ll, "gemm_nt: operand above 3.75 GiB");
-  ADVHIP_REQUIRE(splits >= 1 && splits <= K / 16 && (splits == 1 || slab_stride >= (long long)(M - 1) * ldc + N), "gemm_nt: bad split count %d", splits);
+  ADVHIP_REQUIRE(splits >= 1 && splits <= K / 16 && (splits == 1 || workspace != nullptr || slab_stride >= (long long)(M - 1) * ldc + N),
+                 "gemm_nt: bad split count %d", splits);
   ADVHIP_REQUIRE(tile >= 0 && tile <= 3, "gemm_nt: tile id %d (0 auto, 1 64x64, 2 128x64, 3 128x128)", tile);
   GemmKKArgs g;
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
   g.lda = (int)lda; g.ldb = (int)ldb; g.ldc = (int)ldc;
   g.a_bytes = (unsigned)a_bytes; g.b_bytes = (unsigned)b_bytes;
   g.splits = splits; g.slab = slab_stride; g.rowsum = rowsum_a;
-  if (tile == 0) tile = ((long long)((M + 127) / 128) * ((N + 63) / 64) * splits >= 1536) ? 2 : 1;
-  const int bm = tile == 1 ? 64 : 128, bn = tile == 3 ? 128 : 64;
+  g.rs_slab = rowsum_slab_stride > 0 ? rowsum_slab_stride : M;
+  ADVHIP_REQUIRE(g.rs_slab >= M, "gemm_nt: row-sum slab stride smaller than M");
+  int bm, bn;
+  gemm_nt_tile(M, N, splits, tile, bm, bn);
   g.tiles_m = (M + bm - 1) / bm;
   g.tiles_n = (N + bn - 1) / bn;
   const long long blocks = (long long)g.tiles_m * g.tiles_n * splits;
   ADVHIP_REQUIRE(blocks < (1ll << 31), "gemm_nt: too many tiles");
+  g.part = nullptr; g.cnt = nullptr; g.part_bytes = 0;
+  if (workspace != nullptr && splits > 1) {
+    const long long ntiles = (long long)g.tiles_m * g.tiles_n;
+    const long long cnt_bytes = GEMM_NT_CNT_BYTES;  // a FIXED head: launches of different shapes share one zero-filled workspace
+    ADVHIP_REQUIRE(ntiles * 4 <= cnt_bytes, "gemm_nt: %lld output tiles above the %lld the counter block holds", ntiles, cnt_bytes / 4);
+    const long long part_bytes = ntiles * splits * bm * bn * 4 + (long long)g.tiles_m * splits * bm * 4;
+    ADVHIP_REQUIRE(part_bytes < 0xF0000000ll, "gemm_nt: partial tiles above 3.75 GiB");
+    ADVHIP_REQUIRE(workspace_bytes >= cnt_bytes + part_bytes && ((uintptr_t)workspace & 255) == 0,
+                   "gemm_nt: needs a 256-byte aligned workspace of %lld bytes (got %lld)", cnt_bytes + part_bytes, (long long)workspace_bytes);
+    g.cnt = reinterpret_cast<unsigned*>(workspace);
+    g.part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + cnt_bytes);
+    g.part_bytes = (unsigned)part_bytes;
+  }
   const dim3 grid((unsigned)blocks);
   if (tile == 3) hipLaunchKernelGGL((gemm_kk_dma_kernel<128, 128>), grid, dim3(256), 0, (hipStream_t)stream, g);
   else if (tile == 2) hipLaunchKernelGGL((gemm_kk_dma_kernel<128, 64>), grid, dim3(256), 0, (hipStream_t)stream, g);
+  else if (blocks <= 768) hipLaunchKernelGGL((gemm_kk_dma_kernel<64, 64, 6>), grid, dim3(256), 0, (hipStream_t)stream, g);  // <= 3 workgroups per CU: deep ring
   else hipLaunchKernelGGL((gemm_kk_dma_kernel<64, 64>), grid, dim3(256), 0, (hipStream_t)stream, g);
   return check_launch("gemm_nt");
 }
@@ -2698,11 +2820,53 @@ static int gemm_nt_launch(const float* A, const float* B, float* C, int32_t M, i
 
 extern "C" int advhip_gemm_nt_f32(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda,
                                   int64_t ldb, int64_t ldc, int32_t splits, int64_t slab_stride, void* stream) {
-  return advhip::gemm_nt_launch(A, B, C, M, N, K, lda, ldb, ldc, splits, slab_stride, 0, nullptr, stream);
+  return advhip::gemm_nt_launch(A, B, C, M, N, K, lda, ldb, ldc, splits, slab_stride, 0, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int advhip_gemm_nt_rowsum_f32(const float* A, const float* B, float* C, float* rowsum_a, int32_t M, int32_t N, int32_t K,
                                          int64_t lda, int64_t ldb, int64_t ldc, int32_t splits, int64_t slab_stride, int32_t tile,
                                          void* stream) {
-  return advhip::gemm_nt_launch(A, B, C, M, N, K, lda, ldb, ldc, splits, slab_stride, tile, rowsum_a, stream);
+  return advhip::gemm_nt_launch(A, B, C, M, N, K, lda, ldb, ldc, splits, slab_stride, tile, rowsum_a, nullptr, 0, stream);
+}
+
+// dst[i] = sum over s (in order) of src[s * stride + i]: the K slices of a small NT product and of its row sums, laid out as
+// one [splits][n] matrix, in one pass
+namespace advhip {
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n, int splits,
+                                                        long long stride) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float v = src[i];
+    for (int sl = 1; sl < splits; ++sl) v += src[(long long)sl * stride + i];
+    dst[i] = v;
+  }
+}
+}  // namespace advhip
+
+extern "C" int advhip_gemm_nt_slabs_f32(const float* A, const float* B, float* slabs, int32_t M, int32_t N, int32_t K, int64_t lda,
+                                        int64_t ldb, int32_t splits, int32_t tile, int32_t with_rowsum, void* stream) {
+  const long long stride = (long long)M * N + (with_rowsum ? M : 0);
+  return advhip::gemm_nt_launch(A, B, slabs, M, N, K, lda, ldb, N, splits, stride, tile, with_rowsum ? slabs + (long long)M * N : nullptr,
+                                nullptr, 0, stream, stride);
+}
+
+extern "C" int advhip_sum_slabs_f32(const float* slabs, float* out, int64_t n, int32_t splits, int64_t stride, void* stream) {
+  ADVHIP_REQUIRE(slabs && out && n > 0 && splits >= 1 && stride >= n, "sum_slabs: bad arguments");
+  const int grid = (int)std::min<long long>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(advhip::sum_slabs_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, slabs, out, (long long)n, splits, (long long)stride);
+  return check_launch("sum_slabs");
+}
+
+extern "C" int64_t advhip_gemm_nt_workspace_bytes(int32_t M, int32_t N, int32_t splits, int32_t tile) {
+  if (M <= 0 || N <= 0 || splits <= 1 || tile < 0 || tile > 3) return 0;
+  int bm, bn;
+  advhip::gemm_nt_tile(M, N, splits, tile, bm, bn);
+  const long long tm = (M + bm - 1) / bm, tn = (N + bn - 1) / bn;
+  return advhip::GEMM_NT_CNT_BYTES + tm * tn * splits * bm * bn * 4 + tm * splits * bm * 4;
+}
+
+extern "C" int advhip_gemm_nt_reduced_f32(const float* A, const float* B, float* C, float* rowsum_a, int32_t M, int32_t N, int32_t K,
+                                          int64_t lda, int64_t ldb, int64_t ldc, int32_t splits, int32_t tile, void* workspace,
+                                          int64_t workspace_bytes, void* stream) {
+  ADVHIP_REQUIRE(splits == 1 || workspace != nullptr, "gemm_nt_reduced: K slices need a workspace");
+  return advhip::gemm_nt_launch(A, B, C, M, N, K, lda, ldb, ldc, splits, 0, tile, rowsum_a, workspace, workspace_bytes, stream);
 }

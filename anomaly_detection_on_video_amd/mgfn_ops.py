@@ -33,11 +33,11 @@ _KTABS: Dict[Tuple, torch.Tensor] = {}
 _CONST: Dict[Tuple, torch.Tensor] = {}
 
 
-# smallest channel count that goes to the HIP GEMMs: inference takes the 64-channel layers too (stage 0, the 2048 -> 64
-# token conv: 2.49 vs 2.84 ms per video); with autograd they stay on torch (their weight-gradient GEMMs are tiny and the
-# k = 3 unfold of the 2048-channel input costs more than it saves: 22.5 vs 22.0 ms per training step)
+# smallest channel count that goes to the HIP GEMMs: 64 = every layer of the default model (stage 0 included: at inference
+# 2.49 vs 2.84 ms per video; in a training step at (32,10,32,2049) 17.60 vs 17.94 ms, round 3).  The 2048 -> 64 token conv
+# keeps a torch GEMM with autograd (MGFNFeatureAmplifier._tokens_by_taps: its weight gradient here would unfold the input)
 MIN_CHANNELS_INFER = int(os.environ.get("ADV_MGFN_HIP_MIN_CHANNELS", "64"))
-MIN_CHANNELS_TRAIN = int(os.environ.get("ADV_MGFN_HIP_MIN_CHANNELS_TRAIN", "128"))
+MIN_CHANNELS_TRAIN = int(os.environ.get("ADV_MGFN_HIP_MIN_CHANNELS_TRAIN", "64"))
 
 
 def _on_current_device(x: torch.Tensor) -> bool:

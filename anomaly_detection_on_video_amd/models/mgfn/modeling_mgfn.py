@@ -172,12 +172,26 @@ class MGFNFeatureAmplifier(nn.Module):
         bs, ncrops, t, c = x.shape
         x = x.reshape(bs * ncrops, t, c).permute(2, 0, 1)  # (C+1, B, T) view
         if torch.is_grad_enabled() and self.to_tokens.weight.requires_grad:
-            # with autograd the 2048 -> 64 token conv stays a torch GEMM: its weight gradient on the HIP path would unfold the
-            # 2048-channel input (252 MB) for a 64-row product
-            tokens = _conv_k_torch(self.to_tokens, x[: self.channels])
+            tokens = self._tokens_by_taps(x, bs * ncrops, t)
         else:
             tokens = _conv_k(self.to_tokens, x[: self.channels])
         return tokens + self.mag_ratio * _conv_k(self.to_mag, x[self.channels :])
+
+    def _tokens_by_taps(self, x, b, t):
+        """The 2048 -> 64 token conv with autograd, without unfolding its input: a k-tap conv is linear in its taps,
+        conv_k(x)[o, t] = sum_j (W_j x)[o, t + j - k/2], so ONE GEMM of the stacked tap matrices (k*64 x 2048) with the input AS
+        STORED (positions x channels, read through its strides: no transposed / padded / tap-stacked copy, 84 + 252 MB at the
+        training batch) gives the k per-tap products, and a shifted add over (k*64, B, T) -- 1/32 of the input's size --
+        finishes the conv.  Backward (autograd): dW = dZ X, again on the input as stored; no input gradient."""
+        conv = self.to_tokens
+        o, c, k = conv.weight.shape
+        xv = x[:c].reshape(c, b * t)                                      # (C, B*T) view of the (B*T, C+1) rows: strides (1, C+1)
+        z = torch.matmul(conv.weight.permute(2, 0, 1).reshape(k * o, c), xv).view(k, o, b, t)
+        zp = F.pad(z, (k // 2, k // 2))
+        y = zp[0, :, :, 0:t]
+        for j in range(1, k):
+            y = y + zp[j, :, :, j : j + t]
+        return y + conv.bias.view(-1, 1, 1) if conv.bias is not None else y
 
 
 class GlanceAttention(nn.Module):

@@ -156,6 +156,21 @@ def workspace(dev: torch.device, nbytes: int) -> Optional[torch.Tensor]:
     return ws
 
 
+_ZERO_WORKSPACES: Dict[Tuple[torch.device, int], torch.Tensor] = {}
+
+
+def zeroed_workspace(dev: torch.device, nbytes: int) -> Optional[torch.Tensor]:
+    """Grow-only scratch per (device, launch stream) that is ZERO when handed out for the first time -- for kernels that keep
+    arrival counters in it and leave them zero (advhip_gemm_nt_reduced_f32): zero-filled once per allocation, not per launch."""
+    if nbytes <= 0:
+        return None
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _ZERO_WORKSPACES.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = _ZERO_WORKSPACES[key] = torch.zeros(((nbytes + 3) // 4,), device=dev, dtype=torch.float32)
+    return ws
+
+
 def batch_stride(t: torch.Tensor) -> int:
     """Elements between consecutive samples of an NCDHW tensor that is contiguous per sample: a contiguous tensor,
     or a channel slice `wide[:, a:b]` of one (the kernels take the batch stride; everything inside a sample must be
@@ -465,8 +480,7 @@ def softmax_rows(x: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor
 # (M, N) -> (tile id, K slices) of advhip_gemm_nt_rowsum_f32 at K = 10 240, measured on one MI355X (tools/tune_gemm_nt.py,
 # profiles/r03_gemm_nt_tune.txt): the weight-gradient shapes of the MGFN scorer at its training batch.  Other shapes: heuristic.
 GEMM_NT_TUNED: Dict[Tuple[int, int, int], Tuple[int, int]] = {
-    (4096, 1024, 10240): (3, 4), (1024, 4096, 10240): (3, 3), (1024, 1024, 10240): (3, 8), (1024, 3072, 10240): (3, 4),
-    (1024, 128, 10240): (1, 32), (512, 128, 10240): (1, 32), (128, 512, 10240): (1, 32),
+    (4096, 1024, 10240): (2, 2), (1024, 4096, 10240): (3, 3), (1024, 1024, 10240): (1, 4), (1024, 3072, 10240): (3, 4),
 }
 
 
@@ -478,11 +492,13 @@ def gemm_nt_choice(M: int, N: int, K: int) -> Tuple[int, int]:
     return 0, max(1, min(64, 1024 // max(tiles, 1), K // 256))  # few output tiles (128-channel layers): many K slices
 
 
-def gemm_nt(a: torch.Tensor, b: torch.Tensor, splits: int = 0, rowsum: bool = False, tile: int = 0):
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, splits: int = 0, rowsum: bool = False, tile: int = 0,
+            reduce_in_kernel: Optional[bool] = None):
     """a (M, K) @ b (N, K)^T -> (M, N) for two k-contiguous operands (row pitch = stride(0)); K % 16 == 0.  The weight
     gradient of a GEMM-shaped layer with (channel, position) activations (include/advhip.h: advhip_gemm_nt_rowsum_f32).
-    `splits`: K slices (0 = the measured / heuristic choice); the slices are summed here.  `rowsum`: also return the row
-    sums of `a` (M,) -- the bias gradient of the same layer, out of the same launch."""
+    `splits`: K slices (0 = the measured / heuristic choice), summed inside the launch by the last-arriving workgroup of
+    every tile (slice order: run-to-run bit-identical).  `rowsum`: also return the row sums of `a` (M,) -- the bias gradient
+    of the same layer, out of the same launch."""
     require_gpu(a, b, contiguous=False)
     if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1] or a.stride(1) != 1 or b.stride(1) != 1:
         raise ValueError(f"gemm_nt: need (M,K) and (N,K) with unit inner stride, got {tuple(a.shape)} {a.stride()} / {tuple(b.shape)} {b.stride()}")
@@ -491,11 +507,24 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, splits: int = 0, rowsum: bool = Fa
     if splits <= 0:
         t, splits = gemm_nt_choice(M, N, K)
         tile = tile or t
-    out = torch.empty((splits, M, N), device=a.device, dtype=torch.float32)
-    rs = torch.empty((splits, M), device=a.device, dtype=torch.float32) if rowsum else None
-    check(_lib.load().advhip_gemm_nt_rowsum_f32(ptr(a), ptr(b), ptr(out), ptr(rs), M, N, K, a.stride(0), b.stride(0), N, splits, M * N, tile,
-                                                stream(a)), "gemm_nt")
-    out = out[0] if splits == 1 else out.sum(0)
-    if not rowsum:
-        return out
-    return out, (rs[0] if splits == 1 else rs.sum(0))
+    lib = _lib.load()
+    if splits > 1 and reduce_in_kernel is None:
+        reduce_in_kernel = -(-M // 64) * -(-N // 64) >= 64
+    if splits > 1 and not reduce_in_kernel:
+        # few output tiles: slices to slabs, product and row sums reduced by ONE further launch (the in-kernel form would
+        # leave the whole sum to the last arriver of each of a handful of tiles)
+        n = M * N + (M if rowsum else 0)
+        slabs = torch.empty((splits, n), device=a.device, dtype=torch.float32)
+        res = torch.empty((n,), device=a.device, dtype=torch.float32)
+        check(lib.advhip_gemm_nt_slabs_f32(ptr(a), ptr(b), ptr(slabs), M, N, K, a.stride(0), b.stride(0), splits, tile, int(rowsum), stream(a)),
+              "gemm_nt_slabs")
+        check(lib.advhip_sum_slabs_f32(ptr(slabs), ptr(res), n, splits, n, stream(a)), "sum_slabs")
+        out = res[: M * N].view(M, N)
+        return (out, res[M * N :]) if rowsum else out
+    out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    rs = torch.empty((M,), device=a.device, dtype=torch.float32) if rowsum else None
+    need = lib.advhip_gemm_nt_workspace_bytes(M, N, splits, tile) if splits > 1 else 0
+    ws = zeroed_workspace(a.device, need)  # (arrival counters: zero on entry, left zero by the launch)
+    check(lib.advhip_gemm_nt_reduced_f32(ptr(a), ptr(b), ptr(out), ptr(rs), M, N, K, a.stride(0), b.stride(0), N, splits, tile, ptr(ws), need,
+                                         stream(a)), "gemm_nt")
+    return (out, rs) if rowsum else out

@@ -276,6 +276,25 @@ int advhip_gemm_nt_rowsum_f32(const float* A, const float* B, float* C, float* r
                               int64_t lda, int64_t ldb, int64_t ldc, int32_t splits, int64_t slab_stride, int32_t tile,
                               void* stream);
 
+/* The same with the K slices summed INSIDE the launch: every (tile, slice) workgroup publishes its partial tile (write-through
+ * stores) into `workspace`, the workgroup that arrives last at the tile's counter sums the slices in slice order (run-to-run
+ * bit-identical) and writes C (M x N, pitch ldc) and rowsum_a (M, nullable) once -- no slabs, no second pass.
+ * `workspace`: 256-byte aligned, advhip_gemm_nt_workspace_bytes(M, N, splits, tile) bytes, whose first 64 KiB (the arrival
+ * counters: at most 16 384 output tiles) are ZERO on entry; the launch leaves them zero, so a workspace zero-filled once
+ * serves every later launch -- of any shape -- on the same stream. */
+int64_t advhip_gemm_nt_workspace_bytes(int32_t M, int32_t N, int32_t splits, int32_t tile);
+int advhip_gemm_nt_reduced_f32(const float* A, const float* B, float* C, float* rowsum_a, int32_t M, int32_t N, int32_t K,
+                               int64_t lda, int64_t ldb, int64_t ldc, int32_t splits, int32_t tile, void* workspace,
+                               int64_t workspace_bytes, void* stream);
+
+/* Few output tiles (the 64- and 128-channel layers' weight gradients: M x N of a few 64 x 64 tiles, K = all positions): there
+ * the last arriver's serial sum is the whole tail of the launch, so the slices go to `slabs` = [splits][M*N (+ M row sums when
+ * with_rowsum)] and advhip_sum_slabs_f32 (dst[i] = sum in slice order of src[s*stride + i]) reduces product AND row sums
+ * in one further launch. */
+int advhip_gemm_nt_slabs_f32(const float* A, const float* B, float* slabs, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb,
+                             int32_t splits, int32_t tile, int32_t with_rowsum, void* stream);
+int advhip_sum_slabs_f32(const float* slabs, float* out, int64_t n, int32_t splits, int64_t stride, void* stream);
+
 /* y[r, :] = softmax(x[r, :] * scale) over rows of n contiguous floats (F.softmax(theta_phi * dim_inner**-0.5, dim=-1),
  * src/i3d.py:174-175; the attention softmax of GlanceAttention, modeling_mgfn.py:115-120).  x == y allowed. */
 int advhip_softmax_rows_f32(const float* x, float* y, int64_t rows, int32_t n, float scale, void* stream);

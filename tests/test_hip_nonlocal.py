@@ -224,6 +224,46 @@ def test_gemm_nt_row_sums_and_tiles_vs_torch_fp64(M, N, K, splits, tile):
     assert torch.equal(out, ops.gemm_nt(a, b, splits, tile=tile))  # the product does not depend on the row sums being taken
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3])
+def test_gemm_nt_in_kernel_slice_reduction_equals_the_ordered_slab_sum_under_load(tile):
+    """advhip_gemm_nt_reduced_f32 (partial tiles published write-through, last arriver sums in slice order, counters left
+    zero) against the slab form of the same kernel summed in slice order on the host side of the ABI: bit for bit, C and the
+    row sums, launch after launch on two streams at once (every launch re-uses the counters the previous one left)."""
+    import ctypes as C
+
+    from anomaly_detection_on_video_amd import _lib, ops
+
+    lib = _lib.load()
+    dev = _dev()
+    M, N, K, splits = 320, 448, 4096, 5
+    a = synth_tensor("ntk.a", (M, K), scale=1.0).to(dev)
+    b = synth_tensor("ntk.b", (N, K), scale=1.0).to(dev)
+    slabs = torch.empty((splits, M, N), device=dev)
+    rs_slabs = torch.empty((splits, M), device=dev)
+    _lib.check(lib.advhip_gemm_nt_rowsum_f32(a.data_ptr(), b.data_ptr(), slabs.data_ptr(), rs_slabs.data_ptr(), M, N, K, K, K, N, splits, M * N, tile,
+                                             torch.cuda.current_stream().cuda_stream), "slabs")
+    want, want_rs = slabs[0].clone(), rs_slabs[0].clone()
+    for sl in range(1, splits):
+        want += slabs[sl]
+        want_rs += rs_slabs[sl]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    load = torch.randn(4096, 4096, device=dev)
+    results = []
+    torch.cuda.synchronize()
+    for rep in range(6):
+        for st in streams:
+            with torch.cuda.stream(st):
+                load @ load  # uneven load beside the reductions
+                results.append(ops.gemm_nt(a, b, splits, rowsum=True, tile=tile, reduce_in_kernel=True))
+    torch.cuda.synchronize()
+    for out, rs in results:
+        assert torch.equal(out, want) and torch.equal(rs, want_rs)
+    out, rs = ops.gemm_nt(a, b, splits, rowsum=True, tile=tile, reduce_in_kernel=False)  # slabs + advhip_sum_slabs_f32: the same sums
+    assert torch.equal(out, want) and torch.equal(rs, want_rs)
+    for key, ws in ops._ZERO_WORKSPACES.items():  # every counter (the workspace's first 64 KiB) back at zero
+        assert int(ws[: 65536 // 4].view(torch.int32).abs().sum()) == 0
+
+
 def test_long_video_segment_cache_and_resume(tmp_path):
     """extract_features.py:116-148: long videos are extracted per segment of frames, each segment cached as
     <out>/<name>/<name>_<seg>.npy and re-used when the run is repeated; the stacked result equals the un-segmented one."""
