@@ -88,6 +88,9 @@ struct ConvArgs {
   int To, Ho, Wo;
   int M, Kpad;
   int THWo, HWo, HW, THW;
+  int MP;             // positions per sample in the M index space (dTHWo's divisor): THWo, or THWo rounded up to 4 when a 1x1x1
+                      // conv on rows that are not a multiple of 4 positions long pads every sample's rows (virtually) so that the
+                      // 16-byte A pieces never straddle two samples; positions >= THWo of a sample compute garbage nobody stores
   int tiles_m, tiles_n;
   int relu, vw;       // relu: activation code 0 none, 1 ReLU, 2 GELU (erf)
   int a16;            // 1x1x1 stride-1 conv on 16-byte aligned rows: the A rows go to LDS as 16-byte LDS-DMA pieces (2-deep ring kernels)
@@ -192,7 +195,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[B
     const int mm = m0 + wm * Cfg::WM + rcol;  // this lane's 4 consecutive m in the read phase
     const bool mok = mm < a.M;                // M % 4 == 0 here, so the group is all-in or all-out
     int bb = 0, pp = 0;
-    if (mok) { bb = (int)a.dTHWo.div((unsigned)mm); pp = mm - bb * a.THWo; }
+    if (mok) { bb = (int)a.dTHWo.div((unsigned)mm); pp = mm - bb * a.MP; }
 #pragma unroll
     for (int jn = 0; jn < FN; ++jn) {
       // write phase: 4*FM consecutive m per lane for channel row li
@@ -265,9 +268,13 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[B
     constexpr int RPI = 64 / Cfg::WM;      // channel rows per read instruction (1 or 2)
     const int rrow = lane / Cfg::WM, rcol = lane % Cfg::WM;
     const int mm = m0 + wm * Cfg::WM + rcol;
-    const bool mok = mm < a.M;
+    bool mok = mm < a.M;
     int bb = 0, pp = 0;
-    if (mok) { bb = (int)a.dTHWo.div((unsigned)mm); pp = mm - bb * a.THWo; }
+    if (mok) {
+      bb = (int)a.dTHWo.div((unsigned)mm);
+      pp = mm - bb * a.MP;
+      mok = pp < a.THWo;  // (virtually padded rows: see ConvArgs::MP)
+    }
 #pragma unroll
     for (int jn = 0; jn < FN; ++jn) {
 #pragma unroll
@@ -977,7 +984,8 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
     pvalid = m < a.M;
     if (pvalid) {
       pb = (int)a.dTHWo.div((unsigned)m);
-      const int p = m - pb * a.THWo;
+      const int p = m - pb * a.MP;
+      pvalid = p < a.THWo;
       pot = (int)a.dHWo.div((unsigned)p);
       const int q = p - pot * a.HWo;
       poh = (int)a.dWo.div((unsigned)q);
@@ -1063,7 +1071,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
       const int m4 = m0 + (lane % (BM / 4)) * 4;
       if (m4 < a.M) {
         const int b4 = (int)a.dTHWo.div((unsigned)m4);
-        vbase16 = (unsigned)(b4 * a.x_bstride + (m4 - b4 * a.THWo) + (lane / (BM / 4)) * a.THW) * 4u;
+        vbase16 = (unsigned)(b4 * a.x_bstride + (m4 - b4 * a.MP) + (lane / (BM / 4)) * a.THW) * 4u;
       }
     }
   }
@@ -2286,6 +2294,7 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
   a.HWo = a.Ho * a.Wo; a.THWo = a.To * a.HWo;
   a.HW = d->H * d->W; a.THW = d->T * a.HW;
   a.relu = d->relu;
+  a.MP = a.THWo;
   a.dTHWo = FastDiv::make((unsigned)a.THWo);
   a.dHWo = FastDiv::make((unsigned)a.HWo);
   a.dWo = FastDiv::make((unsigned)a.Wo);
@@ -2338,7 +2347,28 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
       a.y = reinterpret_cast<float*>(workspace);
     }
   }
-  a.tiles_m = (int)((M + BM - 1) / BM);
+  // every tap of every output position inside the input: no validity mask needed
+  const bool nocheck = d->kt == 1 && d->kh == 1 && d->kw == 1 && d->pt == 0 && d->ph == 0 && d->pw == 0 && g.K == g.Kpad;
+  // 1x1x1 stride-1 conv whose rows are not a multiple of 4 positions long (layer 4: 2 x 7 x 7 = 98), 2-deep LDS-DMA ring, unsplit,
+  // plain epilogue: pad every sample's rows to a multiple of 4 IN THE M INDEX SPACE ONLY (ConvArgs::MP), so that the A tile
+  // can go to LDS as 16-byte pieces (a group of 4 positions never straddles two samples; the last group of a row reads
+  // on into the next channel's row -- or past the tensor, where the buffer range check returns zeros -- for positions nobody stores)
+  long long Mv = M;
+  bool a16pad = false;
+  if (nocheck && d->st == 1 && d->sh == 1 && d->sw == 1 && a.THW % 4 != 0 && ((uintptr_t)x & 15) == 0 && c.splits == 1 &&
+      c.algo > ADVHIP_ALGO_DMA2_BASE && c.algo <= ADVHIP_ALGO_DMA2_BASE + 8 && !ln && y_preact == nullptr && dact_z == nullptr) {
+    a.MP = (a.THWo + 3) / 4 * 4;
+    Mv = (long long)d->B * a.MP;
+    if (Mv < (1ll << 31)) {
+      a16pad = true;
+      a.M = (int)Mv;
+      a.dTHWo = FastDiv::make((unsigned)a.MP);
+    } else {
+      a.MP = a.THWo;
+      Mv = M;
+    }
+  }
+  a.tiles_m = (int)((Mv + BM - 1) / BM);
   a.tiles_n = d->Cout / BN;
   a.dTilesN = FastDiv::make((unsigned)a.tiles_n);
   a.dSplits = FastDiv::make((unsigned)c.splits);
@@ -2363,10 +2393,8 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
   // BK = 32 needs Kpad % 32 == 0: the packed weights are padded to 16 rows only, but the k-table
   // marks rows >= K invalid and the weight rows read beyond Kpad must exist -> require it.
   if (BK == 32) ADVHIP_REQUIRE(g.Kpad % 32 == 0, "conv3d: BK=32 variants need K padded to 32 (K=%d)", g.K);
-  // every tap of every output position inside the input: no validity mask needed
-  const bool nocheck = d->kt == 1 && d->kh == 1 && d->kw == 1 && d->pt == 0 && d->ph == 0 && d->pw == 0 && g.K == g.Kpad;
   // ... and rows of 4 consecutive positions contiguous and 16-byte aligned in x: 16-byte LDS-DMA pieces for A
-  a.a16 = (nocheck && d->st == 1 && d->sh == 1 && d->sw == 1 && a.THW % 4 == 0 && xbs % 4 == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0;
+  a.a16 = (a16pad || (nocheck && d->st == 1 && d->sh == 1 && d->sw == 1 && a.THW % 4 == 0 && xbs % 4 == 0 && ((uintptr_t)x & 15) == 0)) ? 1 : 0;
 #define ADVHIP_FAST_CASE(ID, BM_, BN_, BK_)                                                                         \
   case ADVHIP_ALGO_FAST_BASE + ID:                                                                                  \
     if (nocheck) hipLaunchKernelGGL((conv3d_igemm_fast_kernel<BM_, BN_, BK_, false>), grid, dim3(256), 0, st, a);   \
@@ -2477,6 +2505,7 @@ static int fill_pool_args(ConvArgs& a, const advhip_conv3d_desc* d, const Geomet
   a.relu = d->relu;
   a.vw = 1;
   a.a16 = 0;
+  a.MP = a.THWo;
   a.dTHWo = FastDiv::make((unsigned)a.THWo); a.dHWo = FastDiv::make((unsigned)a.HWo); a.dWo = FastDiv::make((unsigned)a.Wo);
   a.kt_ = d->kt; a.kh_ = d->kh; a.kw_ = d->kw;
   a.pad_off = d->pt * d->H * d->W + d->ph * d->W + d->pw;
