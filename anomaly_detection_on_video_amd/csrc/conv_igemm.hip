@@ -2863,9 +2863,18 @@ extern "C" int advhip_gemm_nt_rowsum_f32(const float* A, const float* B, float* 
 namespace advhip {
 __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n, int splits,
                                                         long long stride) {
+  // eight slices are loaded before any is added (the adds stay in slice order): a chain of `splits` dependent loads otherwise
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     float v = src[i];
-    for (int sl = 1; sl < splits; ++sl) v += src[(long long)sl * stride + i];
+    int sl = 1;
+    for (; sl + 8 <= splits; sl += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = src[(long long)(sl + u) * stride + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; sl < splits; ++sl) v += src[(long long)sl * stride + i];
     dst[i] = v;
   }
 }
