@@ -100,6 +100,10 @@ SIGNATURES = {
     "advhip_conv3d_pool_out_dims": (C.c_int, [C.POINTER(ConvDesc)] + [_I] * 6 + [C.POINTER(_I)] * 3),
     "advhip_conv3d_relu_maxpool233_workspace_bytes": (_L, [C.POINTER(ConvDesc)]),
     "advhip_conv3d_bn_relu_maxpool233_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P]),
+    "advhip_split_w_plane_floats": (_I, [_I]),
+    "advhip_split_w_f32": (C.c_int, [_P, _P, _L, _I, _P]),
+    "advhip_conv3d_s2w_build_ktab": (C.c_int, [C.POINTER(ConvDesc), _P, _P]),
+    "advhip_conv3d_s2w_bn_relu_maxpool233_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P]),
     "advhip_conv3d_u8_table_sizes": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "advhip_conv3d_u8_build_tables": (C.c_int, [C.POINTER(ConvDesc), _I, _I, _P, C.c_float, _P, _P, _P]),
     "advhip_conv3d_u8_taps_table_sizes": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
@@ -145,6 +149,7 @@ SIGNATURES = {
     "advhip_mgfn_loss_bwd_f32": (C.c_int, [_P] * 14 + [_I] * 5 + [_P]),
     "advhip_segment_features_f32": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "advhip_add_magnitude_f32": (C.c_int, [_P, _P, _L, _I, _P]),
+    "advhip_tencrop_normalize_planes_u8": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _L, _L, C.c_float, C.c_float, _P]),
     "advhip_tencrop_normalize_u8": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, C.c_float, C.c_float, _P]),
     "advhip_normalize_permute_u8": (C.c_int, [_P, _P, _L, _I, _I, _I, _I, C.c_float, C.c_float, _P]),
 }

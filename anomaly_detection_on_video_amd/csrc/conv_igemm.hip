@@ -94,6 +94,9 @@ struct ConvArgs {
   int tiles_m, tiles_n;
   int relu, vw;       // relu: activation code 0 none, 1 ReLU, 2 GELU (erf)
   int a16;            // 1x1x1 stride-1 conv on 16-byte aligned rows: the A rows go to LDS as 16-byte LDS-DMA pieces (2-deep ring kernels)
+  // AMODE 1 (stride-2-along-w stem on column-parity planes, see split_w_kernel): x = xs (B, Cin, T, H, 2, WP)
+  const int2* ktab_s2w;  // [Kpad] {byte offset of the tap's 4-column piece relative to the group's window origin, (dt, dh) tap bits}
+  int s2w_rowp;          // floats per input row of xs (both parities): 2 * WP
   float* y2;          // nullable: the pre-activation value (after scale/shift/residual), y's addressing -- saved for backward
   const float* dact;  // nullable: z of a GELU, y's addressing (dense): the result is multiplied by gelu'(z) (fused GELU backward)
   // nullable LayerNorm fold (1x1x1 convs over a (C, positions) activation): conv(W.diag(g), x_raw) -> W.LN(x) - W.b:
@@ -932,7 +935,14 @@ constexpr int dma_waves_per_simd() {
   return by_lds > 8 ? 8 : (by_lds < 1 ? 1 : by_lds);
 }
 
-template <int BM, int BN, int BK, bool CHECK, int NS = 3, int EPI = EPI_STD, bool U8 = false>
+// AMODE 1: the A operand of a conv with stride 2 and an odd kernel along w, gathered as 16-byte pieces from COLUMN-PARITY
+// PLANES of the input (xs[b, c, t, h, par, 2 + j] = x[b, c, t, h, 2 j + par], zero columns either side: split_w_kernel).
+// Tap dw of output column ow reads input column 2 ow + dw - pw = plane (dw - pw) & 1, column ow + floor((dw - pw) / 2): for a
+// fixed tap four consecutive output columns read four CONSECUTIVE floats, so one lane fetches the 16 bytes of four positions
+// and one wave-instruction fills two whole k-rows of the [k][128 m] tile -- 2 A instructions per wave and k-tile instead of
+// 8.  The stem is bound by the issue slots its LDS-DMA instructions share with the MFMAs (82 % MFMA-busy); same K order,
+// same operands, same accumulation: bit-identical to the 4-byte gather.
+template <int BM, int BN, int BK, bool CHECK, int NS = 3, int EPI = EPI_STD, bool U8 = false, int AMODE = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dma_waves_per_simd<BM, BN, BK, NS>(), 8)))
 void conv3d_igemm_dma_kernel(const ConvArgs a) {
   using Cfg = IgemmCfg<BM, BN, BK>;
@@ -1039,6 +1049,19 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
     u8c.c[0] = u8c.row[(size_t)wc0 * a.Cout];
     u8c.c[1] = u8c.row[(size_t)wc0 * a.Cout + 1];
   }
+  // AMODE 1: lane (lane & 31) owns the 4-column group (lane & 31) * 4 of the m-tile, lane >> 5 picks the k-row of the pair
+  unsigned vbase_s = OOB, vmask_s = 0;
+  const bool hsel = lane >= 32;
+  if constexpr (AMODE == 1) {
+    static_assert(AMODE == 0 || (EPI == EPI_POOL233 && BM == 128 && BK == 16 && NS == 2 && CHECK && !U8), "column-parity gather: the fused stem form");
+    const int ml4 = (lane & 31) * 4;
+    const int gt = bk_t * BRICK_T + ml4 / (BRICK_H * BRICK_W), gh = bk_h * BRICK_H + (ml4 / BRICK_W) % BRICK_H, gw = bk_w * BRICK_W + ml4 % BRICK_W;
+    if (gt < a.To && gh < a.Ho && gw < a.Wo) {  // (Wo % 4 == 0: a group is all inside or all outside)
+      const int it0 = gt * a.st - a.pt, ih0 = gh * a.sh - a.ph;
+      vbase_s = (unsigned)(bk_b * a.x_bstride + (it0 * a.H + ih0) * a.s2w_rowp + gw + a.pad_off) * 4u;
+      vmask_s = tap_bits(it0, a.kt_, a.T) | (tap_bits(ih0, a.kh_, a.H) << 10);
+    }
+  }
   const auto rx = U8 ? __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(const_cast<float*>(a.x)) - a.pad_off, 0, a.x_bytes, 0x00020000)
                      : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) - a.pad_off, 0, a.x_bytes, 0x00020000);
   const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
@@ -1083,6 +1106,17 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
     float* As = smem + stage * D::STAGE;
     float* Bs = As + BK * BM;
     bool done16 = false;
+    if constexpr (AMODE == 1) {
+      // piece g = k-rows 2 g, 2 g + 1 of the tile (this wave: rows 4 wave .. 4 wave + 3, entries ent[0..7])
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int g = wave * 2 + q;
+        const int eo = hsel ? ent[4 * q + 2] : ent[4 * q], eb = hsel ? ent[4 * q + 3] : ent[4 * q + 1];
+        const unsigned voff = ((vmask_s & (unsigned)eb) == (unsigned)eb) ? vbase_s + (unsigned)eo : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(As + g * 2 * BM), A16_BYTES, voff, 0, 0, 0);
+      }
+      done16 = true;
+    }
     if constexpr (CAN16) {
       if (a16) {
 #pragma unroll
@@ -1110,8 +1144,18 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(Bs + row0 * BN), 16, wvoff, ((k0 + row0) * a.Cout + n0) * 4, 0, 0);
     }
   };
+  auto load_entries = [&](int k0) {
+    if constexpr (AMODE == 1) {
+      int e4[8];
+      sload_entries<4>(a.ktab_s2w, (k0 + wave * 4) * 8, e4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ent[i] = e4[i];
+    } else {
+      if (!a16) sload_entries<LA>(ktab2, (k0 + kr * LA) * 8, ent);
+    }
+  };
   auto issue_tile = [&](int k0, int stage) {
-    if (!a16) sload_entries<LA>(ktab2, (k0 + kr * LA) * 8, ent);
+    load_entries(k0);
     issue_part(k0, stage, 0, 1);
   };
 
@@ -1235,7 +1279,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");  // all waves' parts of tile kt are in LDS; stage (kt-1)%NS is free
     const bool pre = kt + NS - 1 < kt1;
-    if (pre && !a16) sload_entries<LA>(ktab2, ((kt + NS - 1) * BK + kr * LA) * 8, ent);
+    if (pre) load_entries((kt + NS - 1) * BK);
     compute(pre, stage, (kt + NS - 1) * BK, stage == 0 ? NS - 1 : stage - 1);
     stage = stage == NS - 1 ? 0 : stage + 1;
   }
@@ -1966,6 +2010,38 @@ __global__ void build_ktab_kernel(int4* __restrict__ ktab, int kt, int kh, int k
   }
 }
 
+// ---- column-parity planes for a stride-2-along-w conv (conv3d_igemm_dma_kernel<..., AMODE = 1>) ---------------------------
+// xs[row][par][S2W_PADL + j] = x[row][2 j + par] for j < W / 2, zero in the S2W_PADL columns before and the columns after;
+// row = (b, c, t, h), WP = W / 2 + S2W_PAD floats per plane.  One thread per output element.
+constexpr int S2W_PADL = 2, S2W_PAD = 4;
+__global__ __launch_bounds__(256) void split_w_kernel(const float* __restrict__ x, float* __restrict__ xs, long long rows, int W, int WP) {
+  const long long total = rows * 2 * WP;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long rp = i / WP;           // (row, par)
+    const int idx = (int)(i - rp * WP);
+    const long long row = rp >> 1;
+    const int par = (int)(rp & 1), j = idx - S2W_PADL;
+    xs[i] = (j >= 0 && 2 * j + par < W) ? x[row * W + 2 * j + par] : 0.f;
+  }
+}
+
+// {byte offset, (dt, dh) tap bits} per k-row for the parity-plane layout: tap dw of a window whose 4-column group starts at
+// output column ow0 reads plane (dw - pw) & 1, columns ow0 + floor((dw - pw) / 2) + S2W_PADL ... + 3
+__global__ void build_ktab_s2w_kernel(int2* __restrict__ tab, int kt, int kh, int kw, int pw, int K, int Kpad, int H, int T, int WP) {
+  const int taps = kt * kh * kw, rowp = 2 * WP;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < Kpad; k += gridDim.x * blockDim.x) {
+    int2 f = make_int2(0, (int)(1u << 30));  // padding rows: never inside
+    if (k < K) {
+      const int ci = k / taps, tap = k % taps;
+      const int dt = tap / (kh * kw), r = tap % (kh * kw);
+      const int dh = r / kw, dw = r % kw;
+      const int e = dw - pw, par = e & 1, off = (e - par) / 2;  // floor division by 2 (e - par is even)
+      f = make_int2((((ci * T + dt) * H + dh) * rowp + par * WP + off + S2W_PADL) * 4, (int)((1u << dt) | (1u << (10 + dh))));
+    }
+    tab[k] = f;
+  }
+}
+
 // ---- tables of the uint8-frame stem (conv3d_igemm_dma_kernel<..., U8 = true>) ---------------------------------------------
 // {byte offset, tap bits} per k-row for frames stored (F, FH, FW, C): table 0 as stored, table 1 for the mirrored crops
 // (tap dw of a mirrored crop is source column -dw; the kernel moves its window origin (kw-1) columns left to keep offsets >= 0)
@@ -2578,6 +2654,85 @@ extern "C" int advhip_conv3d_bn_relu_maxpool233_f32(const advhip_conv3d_desc* d,
   if (nocheck) hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, false, 2, EPI_POOL233>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, true, 2, EPI_POOL233>), grid, dim3(256), 0, st, a);
   if (int rc = check_launch("conv3d+pool233")) return rc;
+  const unsigned gx = (unsigned)std::min<long long>(rows, 1 << 20), gy = (unsigned)((rows + gx - 1) / gx);
+  hipLaunchKernelGGL(stem_pool_merge_kernel, dim3(gx, gy), dim3(256), (size_t)2 * nbw * 288 * sizeof(float), st, reinterpret_cast<const float*>(workspace), y, d->Cout, Tp,
+                     Hp, Wp, nbh, nbw, a.tiles_n, FastDiv::make((unsigned)Wp), rows, ybs);
+  return check_launch("stem_pool_merge");
+}
+
+// ---- the same stem on column-parity planes of its input (16-byte A pieces for the stride-2 gather) --------------------------
+namespace advhip {
+static int s2w_check(const advhip_conv3d_desc* d, const Geometry& g) {
+  ADVHIP_REQUIRE(d->sw == 2 && d->kw % 2 == 1 && d->pw == d->kw / 2 && d->pw <= 2 * S2W_PADL && d->W % 2 == 0 && d->W >= 8,
+                 "conv3d s2w: needs stride 2, an odd kernel <= %d with 'same' padding along w and an even W (k=%d s=%d p=%d W=%d)",
+                 4 * S2W_PADL + 1, d->kw, d->sw, d->pw, d->W);
+  ADVHIP_REQUIRE(g.Wo % 4 == 0, "conv3d s2w: output width %d is not a multiple of 4", g.Wo);
+  ADVHIP_REQUIRE(d->kt <= 10 && d->kh <= 10, "conv3d s2w: kernel extents above 10");
+  return ADVHIP_OK;
+}
+}  // namespace advhip
+
+extern "C" int32_t advhip_split_w_plane_floats(int32_t W) { return W > 0 && W % 2 == 0 ? W / 2 + advhip::S2W_PAD : -1; }
+
+extern "C" int advhip_split_w_f32(const float* x, float* xs, int64_t rows, int32_t W, void* stream) {
+  ADVHIP_REQUIRE(x && xs && rows > 0 && W > 0 && W % 2 == 0, "split_w: bad arguments");
+  const int WP = W / 2 + S2W_PAD;
+  const long long total = rows * 2 * WP;
+  const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 64);
+  hipLaunchKernelGGL(split_w_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, xs, (long long)rows, W, WP);
+  return check_launch("split_w");
+}
+
+extern "C" int advhip_conv3d_s2w_build_ktab(const advhip_conv3d_desc* d, int32_t* ktab_s2w, void* stream) {
+  if (int rc = validate(d)) return rc;
+  ADVHIP_REQUIRE(ktab_s2w, "conv3d s2w build_ktab: null pointer");
+  const Geometry g = geometry(d);
+  if (int rc = s2w_check(d, g)) return rc;
+  hipLaunchKernelGGL(build_ktab_s2w_kernel, dim3((g.Kpad + 255) / 256), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<int2*>(ktab_s2w), d->kt,
+                     d->kh, d->kw, d->pw, g.K, g.Kpad, d->H, d->T, d->W / 2 + S2W_PAD);
+  return check_launch("build_ktab_s2w");
+}
+
+extern "C" int advhip_conv3d_s2w_bn_relu_maxpool233_f32(const advhip_conv3d_desc* d, const float* xs, int64_t xs_batch_stride,
+                                                        const float* w_packed, const int32_t* ktab_s2w, const float* scale,
+                                                        const float* shift, float* y, int64_t y_batch_stride, void* workspace,
+                                                        int64_t workspace_bytes, void* stream) {
+  if (int rc = validate(d)) return rc;
+  ADVHIP_REQUIRE(xs && w_packed && ktab_s2w && scale && shift && y, "conv3d s2w+pool233: null pointer");
+  const Geometry g = geometry(d);
+  if (int rc = s2w_check(d, g)) return rc;
+  const int Tp = pool_out(g.To, 2, 2), Hp = pool_out(g.Ho, 3, 2), Wp = pool_out(g.Wo, 3, 2);
+  ADVHIP_REQUIRE(Tp > 0 && Hp > 0 && Wp > 0, "conv3d s2w+pool233: conv output (%d,%d,%d) smaller than the (2,3,3) window", g.To, g.Ho, g.Wo);
+  const int64_t need = advhip_conv3d_relu_maxpool233_workspace_bytes(d);
+  ADVHIP_REQUIRE(workspace != nullptr && workspace_bytes >= need && need < 0xF0000000ll,
+                 "conv3d s2w+pool233: needs a %lld-byte workspace (got %lld)", (long long)need, (long long)workspace_bytes);
+  const long long y_dense = (long long)d->Cout * Tp * Hp * Wp;
+  const long long ybs = y_batch_stride > 0 ? y_batch_stride : y_dense;
+  ADVHIP_REQUIRE(ybs >= y_dense, "conv3d s2w+pool233: y batch stride %lld smaller than one pooled sample (%lld)", ybs, y_dense);
+  const int WP = d->W / 2 + S2W_PAD, rowp = 2 * WP;
+  const long long xs_dense = (long long)d->Cin * d->T * d->H * rowp;
+  const long long xbs = xs_batch_stride > 0 ? xs_batch_stride : xs_dense;
+  ADVHIP_REQUIRE(xbs >= xs_dense && ((uintptr_t)xs & 15) == 0, "conv3d s2w+pool233: xs batch stride %lld smaller than one sample (%lld) or xs not 16-byte aligned", xbs, xs_dense);
+  ConvArgs a;
+  if (int rc = fill_pool_args(a, d, g, xs, 0, w_packed, ktab_s2w, scale, shift, false)) return rc;
+  // the gather's view of the input: rows of 2 * WP floats
+  const long long in_elems = (long long)(d->B - 1) * xbs + xs_dense;
+  ADVHIP_REQUIRE(in_elems < (1ll << 30), "conv3d s2w+pool233: input above 4 GiB");
+  a.x_bstride = (int)xbs;
+  a.s2w_rowp = rowp;
+  a.ktab_s2w = reinterpret_cast<const int2*>(ktab_s2w);
+  a.pad_off = (d->pt * d->H + d->ph) * rowp;
+  a.x_bytes = (unsigned)((in_elems + a.pad_off) * 4);
+  a.y = reinterpret_cast<float*>(workspace);  // per-brick partial maxima
+  a.y_bstride = 0; a.Tp = Tp; a.relu = 1;
+  const int nbh = (2 * Hp + 1 + 3) / 4, nbw = (2 * Wp + 1 + 15) / 16;
+  set_bricks(a, Tp, nbh, nbw);
+  ADVHIP_REQUIRE(nbw <= MERGE_MAX_NBW, "conv3d s2w+pool233: pooled width %d above %d", Wp, MERGE_MAX_NBW * 8 - 1);
+  const long long rows = (long long)d->B * a.tiles_n * 2 * Tp * Hp;
+  ADVHIP_REQUIRE(rows < (1ll << 31), "conv3d s2w+pool233: too many output rows");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, true, 2, EPI_POOL233, false, 1>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, st, a);
+  if (int rc = check_launch("conv3d s2w+pool233")) return rc;
   const unsigned gx = (unsigned)std::min<long long>(rows, 1 << 20), gy = (unsigned)((rows + gx - 1) / gx);
   hipLaunchKernelGGL(stem_pool_merge_kernel, dim3(gx, gy), dim3(256), (size_t)2 * nbw * 288 * sizeof(float), st, reinterpret_cast<const float*>(workspace), y, d->Cout, Tp,
                      Hp, Wp, nbh, nbw, a.tiles_n, FastDiv::make((unsigned)Wp), rows, ybs);

@@ -124,9 +124,63 @@ __global__ __launch_bounds__(256) void tencrop_normalize_u8_kernel(const uint8_t
   }
 }
 
+// The same pass writing COLUMN-PARITY PLANES (the operand of the stem's 16-byte gather, advhip_conv3d_s2w_*): crop-clips
+// [first, first + count), xs[(clip-crop, c, t, y)][par][2 + j] = normalised pixel of crop column 2 j + par, zero in the
+// padding columns.  One wave per (row, both planes); the arithmetic per pixel is the pass above's, so the values are its values.
+__global__ __launch_bounds__(256) void tencrop_normalize_planes_u8_kernel(const uint8_t* __restrict__ x, float* __restrict__ xs, int F, int H,
+                                                                          int W, int C, int fpc, int cs, int ctop, int cleft, float mean,
+                                                                          float stdv, long long first, long long rows, int WP) {
+  const int lane = threadIdx.x & 63;
+  for (long long r0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r0 < rows; r0 += (long long)gridDim.x * 4) {
+    long long r = r0;  // (clip-crop - first, c, t, y)
+    const int yo = (int)(r % cs);
+    r /= cs;
+    const int t = (int)(r % fpc);
+    r /= fpc;
+    const int c = (int)(r % C);
+    r = r / C + first;
+    const int crop = (int)(r % 10);
+    const int clip = (int)(r / 10);
+    const int len = min(fpc, F - clip * fpc);
+    const int f = clip * fpc + t % len;
+    const int j5 = crop % 5;
+    const int top = j5 == 4 ? ctop : ((j5 >> 1) ? H - cs : 0), left = j5 == 4 ? cleft : ((j5 & 1) ? W - cs : 0);
+    const uint8_t* row = x + (((long long)f * H + top + yo) * W) * C + c;
+    float* out = xs + r0 * 2 * WP;
+    for (int q = lane; q < 2 * WP; q += 64) {
+      const int par = q >= WP, idx = q - par * WP, xo = 2 * (idx - 2) + par;
+      float v = 0.f;
+      if (idx >= 2 && xo < cs) {
+        const int sx = crop < 5 ? left + xo : W - 1 - (left + xo);
+        v = ((float)row[(long long)sx * C] - mean) / stdv;
+      }
+      out[q] = v;
+    }
+  }
+}
+
 }  // namespace advhip
 
 using namespace advhip;
+
+extern "C" int advhip_tencrop_normalize_planes_u8(const uint8_t* frames, float* xs, int32_t F, int32_t H, int32_t W, int32_t C,
+                                                  int32_t frames_per_clip, int32_t crop, int64_t first_crop_clip, int64_t count, float mean,
+                                                  float stdv, void* stream) {
+  ADVHIP_REQUIRE(frames && xs && F > 0 && C > 0 && frames_per_clip > 0 && crop > 0 && crop % 2 == 0, "tencrop_normalize_planes_u8: bad arguments");
+  ADVHIP_REQUIRE(H >= crop && W >= crop, "tencrop_normalize_planes_u8: frames (%d x %d) smaller than the %d crop", H, W, crop);
+  ADVHIP_REQUIRE(stdv != 0.f, "tencrop_normalize_planes_u8: std must be non-zero");
+  const long long n_clips = (F + frames_per_clip - 1) / frames_per_clip;
+  ADVHIP_REQUIRE(first_crop_clip >= 0 && count > 0 && first_crop_clip + count <= n_clips * 10,
+                 "tencrop_normalize_planes_u8: crop-clips [%lld, %lld) outside the video's %lld", (long long)first_crop_clip,
+                 (long long)(first_crop_clip + count), n_clips * 10);
+  auto half_even = [](int d) { return (d % 2 == 0) ? d / 2 : ((d / 2) % 2 == 0 ? d / 2 : d / 2 + 1); };
+  const int ctop = half_even(H - crop), cleft = half_even(W - crop);
+  const long long rows = (long long)count * C * frames_per_clip * crop;
+  const int grid = (int)std::min<long long>((rows + 3) / 4, 256 * 256);
+  hipLaunchKernelGGL(tencrop_normalize_planes_u8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, xs, F, H, W, C, frames_per_clip,
+                     crop, ctop, cleft, mean, stdv, (long long)first_crop_clip, rows, crop / 2 + 4);
+  return check_launch("tencrop_normalize_planes_u8");
+}
 
 extern "C" int advhip_tencrop_normalize_u8(const uint8_t* frames, float* y, int32_t F, int32_t H, int32_t W, int32_t C,
                                            int32_t frames_per_clip, int32_t crop, float mean, float stdv, void* stream) {

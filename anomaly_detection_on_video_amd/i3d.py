@@ -327,8 +327,15 @@ class I3Res50(nn.Module):
         self.ensure_tables((frames_per_clip, crop, crop), batch)
         if self.frames_fused():
             pc = self._plan[0].convs[0]
-            build = ops.ensure_u8_taps_tables if ops.U8_STEM_FORM == "taps" and pc.cin == 3 and pc.cout == 64 else ops.ensure_u8_tables
+            if self._frames_planes(crop):
+                ops.ensure_ktab_s2w(pc, (frames_per_clip, crop, crop))
+                return
+            build = ops.ensure_u8_taps_tables if ops.U8_STEM_FORM in ("taps", "planes") and pc.cin == 3 and pc.cout == 64 else ops.ensure_u8_tables
             build(pc, tuple(frame_hw), (frames_per_clip, crop, crop))
+
+    def _frames_planes(self, crop: int) -> bool:
+        """forward_frames goes through column-parity planes (TenCrop pass writing them + the 16-byte-gather stem)."""
+        return ops.U8_STEM_FORM == "planes" and ops.s2w_ok(self._plan[0].convs[0], crop)
 
     def forward_frames(self, frames: torch.Tensor, first: int, count: int, frames_per_clip: int = 16, crop: int = 224) -> torch.Tensor:
         """Features (count, 2048, 1, 1, 1) of crop-clips [first, first + count) of a video given as resized uint8 frames
@@ -346,12 +353,19 @@ class I3Res50(nn.Module):
 
                 return self.forward_single(mil_ops.tencrop_normalize_u8(frames, frames_per_clip, crop)[first : first + count])
             stem, pu = self._plan[0], self._plan[0].pool_unit
+            if self._frames_planes(crop):
+                # one pass: TenCrop + float + normalise + permutes, written as column-parity planes; then the stem with 16-byte
+                # gather pieces.  Same arithmetic per pixel as the fp32 pipeline: the features equal model(tencrop_normalize_u8(..)).
+                xs = ops.tencrop_planes_u8(frames, first, count, frames_per_clip, crop)
+                stem_fn = lambda out=None: ops.conv3d_s2w_bn_relu_maxpool233(xs, stem.convs[0], out=out)
+            else:
+                stem_fn = lambda out=None: ops.conv3d_u8_tencrop_bn_relu_maxpool233(frames, stem.convs[0], first, count, frames_per_clip, crop, out=out)
             if pu.cat_channels:  # straight into the [x ; h] buffer of layer1.0, like _Unit.run
                 d = ops.conv_pool_out_dims((frames_per_clip, crop, crop), stem.convs[0], pu.kernel, pu.stride)
                 x = torch.empty((count, stem.convs[0].cout + pu.cat_channels) + d, device=frames.device, dtype=torch.float32)
-                ops.conv3d_u8_tencrop_bn_relu_maxpool233(frames, stem.convs[0], first, count, frames_per_clip, crop, out=x[:, : stem.convs[0].cout])
+                stem_fn(x[:, : stem.convs[0].cout])
             else:
-                x = ops.conv3d_u8_tencrop_bn_relu_maxpool233(frames, stem.convs[0], first, count, frames_per_clip, crop)
+                x = stem_fn()
             for u in self._plan[1:]:
                 if not u.absorbed:
                     x = u.run(x, True)
@@ -376,6 +390,8 @@ class I3Res50(nn.Module):
             elif u.kind in ("stem", "bottleneck"):
                 if u.kind == "bottleneck" and u.convs[3] is not None:
                     ops.ensure_ktab(u.convs[3], dims, batch)  # the downsample branch reads the unit's input
+                if u.kind == "stem" and ops.STEM_S2W and ops.s2w_ok(u.convs[0], dims[2]):
+                    ops.ensure_ktab_s2w(u.convs[0], dims)  # the fused stem's column-parity gather table
                 for c in u.convs[:3]:
                     ops.ensure_ktab(c, dims, batch)
                     dims = ops.conv_out_dims(dims, c.kernel, c.stride, c.padding)

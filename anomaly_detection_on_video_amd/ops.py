@@ -42,6 +42,7 @@ class PackedConv:
     scale: torch.Tensor
     shift: torch.Tensor
     ktabs: Dict[Tuple[int, int, int], torch.Tensor] = field(default_factory=dict)
+    ktabs_s2w: Dict[Tuple[int, int, int], torch.Tensor] = field(default_factory=dict)  # column-parity gather tables (stem)
     algo: int = _lib.ALGO_AUTO
     name: str = ""
     splits: int = 0  # 0 = library heuristic
@@ -227,9 +228,98 @@ def conv_pool_out_dims(in_thw: Sequence[int], pc: "PackedConv", pool_kernel, poo
     return conv_out_dims(conv_out_dims(in_thw, pc.kernel, pc.stride, pc.padding), _triple(pool_kernel), _triple(pool_stride), (0, 0, 0))
 
 
-def conv3d_bn_relu_maxpool233(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+# The fused stem can gather 16-byte pieces from column-parity planes of its input (advhip.h: advhip_conv3d_s2w_*): the conv
+# launch is 6.5 % faster (2.25 vs 2.41 ms at B = 32), the planes cost a pass over the input (0.145 ms for an fp32 NCDHW
+# tensor).  For resized uint8 frames the TenCrop / normalise pass writes the planes itself, so that path uses them by default
+# (U8_STEM_FORM "planes"); for an fp32 NCDHW input the extra pass cancels the gain in isolation and adds 0.6 GB of HBM
+# traffic per step for +0.3 % in the three-lane stream: opt-in (ADV_STEM_S2W=1).
+STEM_S2W = os.environ.get("ADV_STEM_S2W", "0") == "1"
+
+
+def s2w_ok(pc: PackedConv, W: int) -> bool:
+    """Stride 2, odd kernel <= 9 with padding kw // 2 along w, W even and W / 2 a multiple of 4 (advhip.h: advhip_conv3d_s2w_*)."""
+    kw, sw, pw = pc.kernel[2], pc.stride[2], pc.padding[2]
+    return sw == 2 and kw % 2 == 1 and pw == kw // 2 and pw <= 4 and W % 8 == 0 and W >= 8 and pc.kernel[0] <= 10 and pc.kernel[1] <= 10
+
+
+def split_w(x: torch.Tensor) -> torch.Tensor:
+    """(B, C, T, H, W) contiguous -> (B, C, T, H, 2, W/2 + 4): the even and odd columns of every row as two zero-padded planes
+    (one HIP pass; the operand of the stem's 16-byte gather, include/advhip.h: advhip_split_w_f32)."""
+    require_gpu(x)
+    B, Cc, T, H, W = x.shape
+    lib = _lib.load()
+    wp = lib.advhip_split_w_plane_floats(W)
+    if wp < 0:
+        raise ValueError(f"split_w: W = {W} must be even")
+    xs = torch.empty((B, Cc, T, H, 2, wp), device=x.device, dtype=torch.float32)
+    check(lib.advhip_split_w_f32(ptr(x), ptr(xs), B * Cc * T * H, W, stream(x)), "split_w")
+    return xs
+
+
+def ensure_ktab_s2w(pc: PackedConv, thw: Tuple[int, int, int]) -> torch.Tensor:
+    tab = pc.ktabs_s2w.get(thw)
+    if tab is None:
+        d = pc.desc(1, *thw, relu=True, algo=0, splits=1)
+        tab = torch.empty((_packed_rows(d) * 2,), device=pc.w_packed.device, dtype=torch.int32)
+        check(_lib.load().advhip_conv3d_s2w_build_ktab(C.byref(d), ptr(tab), stream()), "build_ktab_s2w")
+        pc.ktabs_s2w[thw] = tab
+    return tab
+
+
+def conv3d_s2w_bn_relu_maxpool233(xs: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The fused stem on column-parity planes xs (B, Cin, T, H, 2, W/2 + 4) of its input (split_w / tencrop_planes_u8)."""
+    require_gpu(xs)
+    require_gpu(out, contiguous=False)
+    if xs.dim() != 6 or xs.shape[1] != pc.cin or xs.shape[4] != 2:
+        raise ValueError(f"{pc.name}: expected planes (B,{pc.cin},T,H,2,W/2+4), got {tuple(xs.shape)}")
+    B, _, T, H, _, wp = xs.shape
+    W = 2 * (wp - 4)
+    if not s2w_ok(pc, W):
+        raise ValueError(f"{pc.name}: the column-parity gather does not apply to W = {W} with k/s/p {pc.kernel[2]}/{pc.stride[2]}/{pc.padding[2]}")
+    d = pc.desc(B, T, H, W, True, 0, 1)
+    lib = _lib.load()
+    tp, hp, wpo = C.c_int32(), C.c_int32(), C.c_int32()
+    check(lib.advhip_conv3d_pool_out_dims(C.byref(d), 2, 3, 3, 2, 2, 2, C.byref(tp), C.byref(hp), C.byref(wpo)), "conv3d_pool_out_dims")
+    shape = (B, pc.cout, tp.value, hp.value, wpo.value)
+    if min(shape) <= 0:
+        raise ValueError(f"{pc.name}: input too small for conv + (2,3,3) pooling")
+    y = out if out is not None else torch.empty(shape, device=xs.device, dtype=torch.float32)
+    if tuple(y.shape) != shape or y.dtype != torch.float32 or y.device != xs.device:
+        raise ValueError(f"{pc.name}: out {tuple(y.shape)} != {shape}")
+    need = lib.advhip_conv3d_relu_maxpool233_workspace_bytes(C.byref(d))
+    if need < 0:
+        check(int(need), f"conv3d_relu_maxpool233_workspace_bytes[{pc.name}]")
+    ws = workspace(xs.device, need)
+    check(lib.advhip_conv3d_s2w_bn_relu_maxpool233_f32(C.byref(d), ptr(xs), 0, ptr(pc.w_packed), ptr(ensure_ktab_s2w(pc, (T, H, W))), ptr(pc.scale),
+                                                       ptr(pc.shift), ptr(y), batch_stride(y), ptr(ws), need, stream(xs)), f"conv3d s2w+pool233[{pc.name}]")
+    return y
+
+
+def tencrop_planes_u8(frames: torch.Tensor, first: int, count: int, frames_per_clip: int = 16, crop: int = 224, mean: float = 114.75,
+                      std: float = 57.375) -> torch.Tensor:
+    """Resized uint8 frames (F, H, W, C) -> column-parity planes (count, C, frames_per_clip, crop, 2, crop/2 + 4) of crop-clips
+    [first, first + count) (row = clip * 10 + crop): TenCrop, float, normalise, LoopPad and the layout permutes of
+    TenCropVideoFrameDataset / _extract (src/dataset.py:175-195, src/gtransforms.py, extract_features.py:83) in one HIP pass,
+    written as the operand of the stem's 16-byte gather.  Values = mil_ops.tencrop_normalize_u8's."""
+    frames = frames.contiguous()
+    require_gpu(frames)
+    if frames.dtype != torch.uint8 or frames.dim() != 4:
+        raise ValueError(f"expected uint8 (F,H,W,C), got {frames.dtype} {tuple(frames.shape)}")
+    f, h, w, c = frames.shape
+    n = -(-f // frames_per_clip) * 10
+    if h < crop or w < crop or crop % 2 or first < 0 or count <= 0 or first + count > n:
+        raise ValueError(f"tencrop_planes_u8: crop-clips [{first},{first + count}) of {n}, frames {h}x{w}, crop {crop}")
+    xs = torch.empty((count, c, frames_per_clip, crop, 2, crop // 2 + 4), device=frames.device, dtype=torch.float32)
+    check(_lib.load().advhip_tencrop_normalize_planes_u8(ptr(frames), ptr(xs), f, h, w, c, frames_per_clip, crop, first, count, C.c_float(mean),
+                                                         C.c_float(std), stream(frames)), "tencrop_normalize_planes_u8")
+    return xs
+
+
+def conv3d_bn_relu_maxpool233(x: torch.Tensor, pc: PackedConv, out: Optional[torch.Tensor] = None, s2w: Optional[bool] = None) -> torch.Tensor:
     """maxpool3d(relu(conv3d(x) * scale + shift), (2,3,3), (2,2,2)) without the un-pooled activation ever reaching HBM
-    (the stem of I3Res50, src/i3d.py:303-306).  Bit-identical to conv3d_bn_act(relu=True) + maxpool3d."""
+    (the stem of I3Res50, src/i3d.py:303-306).  Bit-identical to conv3d_bn_act(relu=True) + maxpool3d.  `s2w` (default: where
+    the geometry allows): gather 16-byte pieces from column-parity planes of x (one extra pass over x, 4x fewer gather
+    instructions in the conv; same results bit for bit)."""
     require_gpu(x, out, contiguous=False)
     if x.dim() != 5 or x.shape[1] != pc.cin:
         raise ValueError(f"{pc.name}: expected (B,{pc.cin},T,H,W), got {tuple(x.shape)}")
@@ -249,6 +339,10 @@ def conv3d_bn_relu_maxpool233(x: torch.Tensor, pc: PackedConv, out: Optional[tor
     if need < 0:
         check(int(need), f"conv3d_relu_maxpool233_workspace_bytes[{pc.name}]")
     ws = workspace(x.device, need)
+    if s2w is None:
+        s2w = STEM_S2W
+    if s2w and s2w_ok(pc, W) and x.is_contiguous():
+        return conv3d_s2w_bn_relu_maxpool233(split_w(x), pc, out=y)
     xbs, ybs = batch_stride(x), batch_stride(y)
     check(lib.advhip_conv3d_bn_relu_maxpool233_f32(C.byref(d), ptr(x), xbs, ptr(pc.w_packed), ptr(ktab), ptr(pc.scale), ptr(pc.shift),
                                                    ptr(y), ybs, ptr(ws), need, stream()), f"conv3d+pool233[{pc.name}]")
@@ -258,7 +352,11 @@ def conv3d_bn_relu_maxpool233(x: torch.Tensor, pc: PackedConv, out: Optional[tor
 PIXEL_MEAN, PIXEL_STD = 114.75, 57.375  # GroupNormalize constants, src/dataset.py:180-181
 
 
-U8_STEM_FORM = os.environ.get("ADV_U8_STEM", "taps")  # "taps": whole pixels (one 4-byte gather per tap), "bytes": one byte gather per (channel, tap)
+# how forward_frames feeds the stem from resized uint8 frames: "planes" (default where the geometry allows): one TenCrop /
+# normalise pass writing column-parity planes + the 16-byte-gather stem (features equal the fp32 pipeline's bit for bit);
+# "taps": the stem kernel reads whole pixels itself (one 4-byte gather per tap, no fp32 tensor at all); "bytes": one byte
+# gather per (channel, tap)
+U8_STEM_FORM = os.environ.get("ADV_U8_STEM", "planes")
 
 
 def readable_bytes(t: torch.Tensor) -> int:
@@ -343,7 +441,7 @@ def conv3d_u8_tencrop_bn_relu_maxpool233(frames: torch.Tensor, pc: "PackedConv",
     if need < 0:
         check(int(need), f"conv3d_relu_maxpool233_workspace_bytes[{pc.name}]")
     ws = workspace(frames.device, need)
-    if U8_STEM_FORM == "taps" and pc.cin == 3 and pc.cout == 64:
+    if U8_STEM_FORM in ("taps", "planes") and pc.cin == 3 and pc.cout == 64:
         frames = with_slack(frames)
         ktab, corr, wt = ensure_u8_taps_tables(pc, (FH, FW), (frames_per_clip, crop, crop), mean)
         check(lib.advhip_conv3d_u8_taps_tencrop_bn_relu_maxpool233_f32(C.byref(d), ptr(frames), F, FH, FW, readable_bytes(frames), first, ptr(wt),

@@ -357,9 +357,10 @@ def main():
             torch.cuda.synchronize()
             return batch * args.steps / (time.perf_counter() - t1)
 
-        # (a) what a decoder + GroupResize(256) hand over: 4 clips = 64 resized uint8 frames per step; the stem kernel reads the
-        #     pixels itself (TenCrop + float + normalise in its load stage) -> 40 crop-clips; beside it the resident rate of
-        #     that same 40-crop-clip batch
+        # (a) what a decoder + GroupResize(256) hand over: 4 clips = 64 resized uint8 frames per step -> 40 crop-clips through
+        #     I3Res50.forward_frames (one TenCrop + float + normalise pass writing column-parity planes, then the stem with
+        #     16-byte gather pieces; ADV_U8_STEM=taps: the stem kernel reads the pixels itself); beside it the resident rate
+        #     of that same 40-crop-clip batch
         fr = torch.randint(0, 256, (64, 256, 341, 3), dtype=torch.uint8).pin_memory()
         stream40 = ExtractScoreStream(backbone, scorer, clips_per_video=32, ncrops=10, local_batch=40, world=1, rank=0)
         x40 = torch.randn((40, 3, 16, 224, 224), device=dev, generator=gen)
@@ -373,7 +374,8 @@ def main():
             "note": "host buffers every step (pinned), copy on the step's lane; never the headline `value`",
             "resized_frames_u8": {"clips_per_s": round(frames40, 2), "crop_clips_per_step": 40, "h2d_bytes_per_step": fr.numel(),
                                   "resident_same_batch_clips_per_s": round(res40, 2), "ratio_to_resident": round(frames40 / res40, 4),
-                                  "input": "64 uint8 frames 256x341x3 (4 clips) -> TenCrop/normalise inside the stem kernel"},
+                                  "input": "64 uint8 frames 256x341x3 (4 clips) -> I3Res50.forward_frames",
+                                  "u8_stem_form": aops.U8_STEM_FORM},
             "fp32_crops": {"clips_per_s": round(fp32_32, 2), "crop_clips_per_step": args.batch, "h2d_bytes_per_step": xh.numel() * 4,
                            "ratio_to_resident": None, "input": "fp32 (32,3,16,224,224) host tensor, the reference's hand-over"},
         }

@@ -173,6 +173,31 @@ int advhip_conv3d_bn_relu_maxpool233_f32(const advhip_conv3d_desc* d, const floa
                                          float* y, int64_t y_batch_stride, void* workspace, int64_t workspace_bytes,
                                          void* stream);
 
+/* --- the same stem with 16-byte gather pieces: column-parity planes of the input ------------------------------------------------
+ * The stem's stride-2 window along w makes its A gather one 4-byte LDS-DMA per (tap, position), and the issue slots those
+ * instructions share with the MFMAs are what bounds the kernel.  With the input rewritten as column-parity planes
+ *   xs[b, c, t, h, par, 2 + j] = x[b, c, t, h, 2 j + par]   (advhip_split_w_f32; WP = advhip_split_w_plane_floats(W) = W/2 + 4
+ *   floats per plane, zero columns either side)
+ * tap dw of four consecutive output columns reads four CONSECUTIVE floats of plane (dw - pw) & 1: one 16-byte piece per lane,
+ * two whole k-rows of the tile per wave-instruction (4x fewer A instructions).  Same K order, operands and accumulation as
+ * advhip_conv3d_bn_relu_maxpool233_f32: bit-identical results.  Needs stride 2, an odd kernel <= 9 with padding kw/2 along w,
+ * W even and an output width that is a multiple of 4 (the I3D stem: 7 / 2 / 3, 224 -> 112).  ktab_s2w: int32[2 * Kpad]. */
+int32_t advhip_split_w_plane_floats(int32_t W);
+int advhip_split_w_f32(const float* x, float* xs, int64_t rows, int32_t W, void* stream);
+int advhip_conv3d_s2w_build_ktab(const advhip_conv3d_desc* d, int32_t* ktab_s2w, void* stream);
+int advhip_conv3d_s2w_bn_relu_maxpool233_f32(const advhip_conv3d_desc* d, const float* xs, int64_t xs_batch_stride,
+                                             const float* w_packed, const int32_t* ktab_s2w, const float* scale, const float* shift,
+                                             float* y, int64_t y_batch_stride, void* workspace, int64_t workspace_bytes,
+                                             void* stream);
+
+/* TenCrop + float + normalise + the layout permutes (advhip_tencrop_normalize_u8 below) writing those planes directly for
+ * crop-clips [first_crop_clip, first_crop_clip + count) of a video: xs (count, C, frames_per_clip, crop, 2, crop/2 + 4).  The
+ * real-data path in front of advhip_conv3d_s2w_bn_relu_maxpool233_f32: the planes cost the pass nothing extra, and the values
+ * are those of advhip_tencrop_normalize_u8 (same arithmetic per pixel), so the features equal the fp32 pipeline's bit for bit. */
+int advhip_tencrop_normalize_planes_u8(const uint8_t* frames, float* xs, int32_t F, int32_t H, int32_t W, int32_t C,
+                                       int32_t frames_per_clip, int32_t crop, int64_t first_crop_clip, int64_t count, float mean,
+                                       float stdv, void* stream);
+
 /* --- the same stem, fed by resized uint8 frames (src/gtransforms.py:29-38,57-73 + extract_features.py:83-89 in the load stage)
  * frames: uint8 (F, FH, FW, Cin) -- what the decoder + GroupResize hand over -- F a whole number of clips of d->T frames.
  * Sample b of the launch (d->B of them) is crop-clip first_crop_clip + b = clip * 10 + crop in torchvision's TenCrop order

@@ -59,6 +59,41 @@ def test_stem_conv_relu_maxpool233_is_bit_exact(shape):
     assert torch.equal(wide[:, :64], fused) and (wide[:, 64:] == -7.0).all()
 
 
+S2W_CASES = [  # (name, cin, cout, kernel, stride, padding, (B, T, H, W)): stride 2 / odd kernel / 'same' padding along w, W % 8 == 0
+    ("stem", 3, 64, (5, 7, 7), (2, 2, 2), (2, 3, 3), (2, 16, 224, 224)),
+    ("stem", 3, 64, (5, 7, 7), (2, 2, 2), (2, 3, 3), (1, 4, 38, 40)),     # H not a multiple of the brick, whole bricks outside
+    ("stem", 3, 64, (5, 7, 7), (2, 2, 2), (2, 3, 3), (2, 5, 11, 16)),     # the smallest widths
+    ("stem", 3, 64, (5, 7, 7), (2, 2, 2), (2, 3, 3), (1, 16, 64, 232)),   # Wo = 116: bricks past the last column
+    ("s555", 8, 64, (5, 5, 5), (2, 2, 2), (2, 2, 2), (2, 6, 30, 48)),     # kw = 5, pw = 2
+    ("s133", 16, 128, (1, 3, 3), (1, 1, 2), (0, 1, 1), (1, 4, 21, 64)),   # kw = 3, stride 2 along w only, two n-tiles
+    ("s379", 4, 64, (3, 7, 9), (1, 2, 2), (1, 3, 4), (1, 4, 20, 24)),     # kw = 9, pw = 4 (the widest the planes' padding admits)
+]
+
+
+@pytest.mark.parametrize("case", S2W_CASES, ids=[f"{c[0]}-{c[6]}" for c in S2W_CASES])
+def test_column_parity_gather_is_bit_identical_to_the_plain_gather(case):
+    """advhip_conv3d_s2w_bn_relu_maxpool233_f32 (16-byte pieces from column-parity planes of the input) against the 4-byte
+    gather from the NCDHW input: same K order, operands and accumulation -> torch.equal; and against conv + maxpool3d."""
+    from anomaly_detection_on_video_amd import ops
+
+    name, cin, cout, k, st, pd, (b, t, h, w) = case
+    pc, _ = _pack(name, cin, cout, k, st, pd)
+    assert ops.s2w_ok(pc, w)
+    x = synth_tensor(f"fp.s2w.{name}.x{(b, t, h, w)}", (b, cin, t, h, w), scale=2.0).to(_dev())
+    xs = ops.split_w(x)
+    assert xs.shape == (b, cin, t, h, 2, w // 2 + 4)
+    assert torch.equal(xs[..., 0, 2 : 2 + w // 2], x[..., 0::2]) and torch.equal(xs[..., 1, 2 : 2 + w // 2], x[..., 1::2])
+    assert float(xs[..., :2].abs().max()) == 0.0 and float(xs[..., 2 + w // 2 :].abs().max()) == 0.0
+    plain = ops.conv3d_bn_relu_maxpool233(x, pc, s2w=False)
+    planes = ops.conv3d_bn_relu_maxpool233(x, pc, s2w=True)
+    assert torch.equal(planes, plain), f"max diff {float((planes - plain).abs().max()):.3e}"
+    unfused = ops.maxpool3d(ops.conv3d_bn_act(x, pc, relu=True, algo=162), (2, 3, 3), (2, 2, 2))
+    assert torch.equal(planes, unfused)
+    wide = torch.full((b, cout + 32) + tuple(plain.shape[2:]), -7.0, device=_dev())
+    ops.conv3d_bn_relu_maxpool233(x, pc, out=wide[:, :cout], s2w=True)
+    assert torch.equal(wide[:, :cout], plain) and (wide[:, cout:] == -7.0).all()
+
+
 def test_conv_relu_maxpool233_other_convs():
     """Not only the stem: any conv the LDS-DMA kernel runs (here a padded 3x3x3 and an un-padded 1x1x1, Cout 128)."""
     from anomaly_detection_on_video_amd import ops

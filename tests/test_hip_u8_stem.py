@@ -51,9 +51,10 @@ CASES = [
 ]
 
 
-@pytest.fixture(params=["taps", "bytes"])
+@pytest.fixture(params=["taps", "bytes", "planes"])
 def form(request, monkeypatch):
-    """Both uint8 stems: whole pixels per gather (the default) and one byte per (channel, tap)."""
+    """The uint8 stems: whole pixels per gather, one byte per (channel, tap), and (forward_frames only; the stem entry point
+    itself then runs the whole-pixel form) the TenCrop pass writing column-parity planes + the 16-byte-gather stem."""
     from anomaly_detection_on_video_amd import ops
 
     monkeypatch.setattr(ops, "U8_STEM_FORM", request.param)
@@ -135,6 +136,10 @@ def test_forward_frames_whole_backbone_and_fallback(form):
     assert got.shape == ref.shape == (40, 2048, 1, 1, 1)
     assert rel_err(got.cpu(), ref.cpu()) < 1e-5
     assert_close_elementwise(got.cpu(), ref.cpu())
+    if form == "planes":  # same arithmetic per pixel, same K order: the fp32 pipeline's features bit for bit, launch shape for
+        assert m._frames_planes(224)  # launch shape (a direct model(x) call cuts its batch over two streams: other tile choices)
+        m.streams = 1
+        assert torch.equal(m.forward_frames(fd, 0, 40), m.forward_single(mil_ops.tencrop_normalize_u8(fd, 16, 224)))
     m.fuse_pool = False
     assert not m.frames_fused()
     assert torch.equal(m.forward_frames(fd, 5, 4), m(mil_ops.tencrop_normalize_u8(fd, 16, 224)[5:9]))
@@ -210,3 +215,20 @@ def test_u8_stem_at_the_reference_geometry_vs_oracle(form):
     assert got.shape == want.shape == (20, 64, 4, 55, 55)
     assert rel_err(got, want) < 2e-5
     assert_close_elementwise(got, want)
+
+
+@pytest.mark.parametrize("case", [((32, 256, 340), 16, 224, (0, 20)), ((20, 40, 52), 8, 32, (7, 11)), ((6, 24, 24), 6, 24, (0, 10)), ((13, 30, 44), 4, 16, (5, 33))],
+                         ids=["reference-geometry", "mid-clip-range", "crop==frame", "short-last-clip"])
+def test_tencrop_planes_pass_equals_the_two_pass_form(case):
+    """advhip_tencrop_normalize_planes_u8 (TenCrop + float + normalise + LoopPad + permutes written as column-parity planes for a
+    range of crop-clips) against advhip_tencrop_normalize_u8 followed by advhip_split_w_f32: bit for bit, padding columns zero."""
+    from anomaly_detection_on_video_amd import mil_ops, ops
+
+    (F, FH, FW), fpc, crop, (first, count) = case
+    fd = torch.from_numpy(_frames(F + FH, (F, FH, FW, 3))).to(_dev())
+    want = ops.split_w(mil_ops.tencrop_normalize_u8(fd, fpc, crop)[first : first + count].contiguous())
+    got = ops.tencrop_planes_u8(fd, first, count, fpc, crop)
+    assert got.shape == want.shape == (count, 3, fpc, crop, 2, crop // 2 + 4)
+    assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        ops.tencrop_planes_u8(fd, first, 10 * (-(-F // fpc)) - first + 1, fpc, crop)
