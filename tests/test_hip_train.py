@@ -328,3 +328,48 @@ def test_end_to_end_extract_segment_train_auc(tmp_path):
     cpu_auc, _ = metrics.frame_level_auc(preds, labels, 16)
     assert abs(cpu_auc - gpu_auc) < 2e-3, (cpu_auc, gpu_auc)
     assert 0.0 <= gpu_auc <= 1.0
+
+
+def test_graphed_training_steps_equal_eager_steps_bit_for_bit():
+    """train_graph.GraphedTrainStep (the step the Trainer and bench.py run: 3 eager steps, then ONE HIP-graph replay per step)
+    against the plain eager loop on an identical model: same batches, keep mask pinned -> after 6 steps the losses and every
+    parameter, BatchNorm running statistic and Adam moment must be IDENTICAL (same kernels, same order, same arithmetic;
+    the graph only removes the host from the loop).  Also: a batch of another shape falls back to the eager step."""
+    from anomaly_detection_on_video_amd.models.mgfn import MGFNConfig, MGFNForVideoAnomalyDetection
+    from anomaly_detection_on_video_amd.train_graph import GraphedTrainStep
+
+    def make():
+        m = MGFNForVideoAnomalyDetection(MGFNConfig())
+        m.load_state_dict(synth_module_state_dict(m))
+        m = m.to(DEV).train()
+        ones = torch.ones(2, 32, device=DEV)
+        m.injected_keep = (ones, ones)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-4, fused=True, capturable=True)
+        return m, opt
+
+    nl, al = torch.zeros(2, device=DEV), torch.ones(2, device=DEV)
+    batches = [mgfn_inputs(4, 32, 40 + i).to(DEV) for i in range(6)]
+    m_e, opt_e = make()
+    eager = GraphedTrainStep(m_e, opt_e, eager_steps=1 << 30)
+    losses_e = [float(eager(b, al, nl)) for b in batches]
+    assert eager.graph is None and eager.replays == 0
+    m_g, opt_g = make()
+    graphed = GraphedTrainStep(m_g, opt_g, eager_steps=3)
+    losses_g = [float(graphed(b, al, nl)) for b in batches]
+    assert graphed.graph is not None and graphed.replays == 3
+    assert losses_g == losses_e, (losses_g, losses_e)
+    assert losses_e[0] != losses_e[-1]
+    for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
+        assert torch.equal(a, b), k
+    for pe, pg in zip(m_e.parameters(), m_g.parameters()):
+        se, sg = opt_e.state[pe], opt_g.state[pg]
+        assert torch.equal(se["exp_avg"], sg["exp_avg"]) and torch.equal(se["exp_avg_sq"], sg["exp_avg_sq"]) and torch.equal(se["step"], sg["step"])
+    # another batch shape: eager fallback, the captured graph stays valid for the original shape afterwards
+    odd = mgfn_inputs(2, 32, 77).to(DEV)
+    m_g.injected_keep = (torch.ones(1, 32, device=DEV), torch.ones(1, 32, device=DEV))
+    loss_odd = graphed(odd, al[:1], nl[:1])
+    assert torch.isfinite(loss_odd) and graphed.replays == 3
+    ones = torch.ones(2, 32, device=DEV)
+    m_g.injected_keep = (ones, ones)
+    # (the captured graph holds the ORIGINAL keep tensors: pinned masks are part of the capture)
+    assert torch.isfinite(graphed(batches[0], al, nl)) and graphed.replays == 4
