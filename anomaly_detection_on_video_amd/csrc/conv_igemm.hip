@@ -1963,12 +1963,27 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* 
 }
 
 // ---- weight packing + gather table -------------------------------------------------------------
-__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int K, int Kpad) {
-  const long long total = (long long)Kpad * Cout;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(i / Cout), co = (int)(i % Cout);
-    wp[i] = (k < K) ? w[(size_t)co * K + k] : 0.f;
+// wp[k][co] = w[co][k] (zero rows for K <= k < Kpad): a 32 x 32-tile transpose through LDS, so that both the reads (k
+// contiguous) and the writes (co contiguous) are coalesced -- the MGFN training step re-packs every GEMM weight each step
+// (4 M elements per stage-2 FFN matrix: 21-25 us for the one-thread-per-element form, whose reads strode by K).
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int K, int Kpad) {
+  __shared__ float tile[32][33];
+  const int tiles_k = (Kpad + 31) / 32, tiles_c = (Cout + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int t = blockIdx.x; t < tiles_k * tiles_c; t += gridDim.x) {
+    const int k0 = (t % tiles_k) * 32, c0 = (t / tiles_k) * 32;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+      const int co = c0 + r, k = k0 + tx;
+      tile[r][tx] = (co < Cout && k < K) ? w[(size_t)co * K + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+      const int k = k0 + r, co = c0 + tx;
+      if (k < Kpad && co < Cout) wp[(size_t)k * Cout + co] = tile[tx][r];
+    }
+    __syncthreads();
   }
 }
 
@@ -2153,8 +2168,8 @@ extern "C" int advhip_conv3d_pack_weight_f32(const advhip_conv3d_desc* d, const 
   ADVHIP_REQUIRE(w && w_packed, "pack_weight: null pointer");
   const int K = d->Cin * d->kt * d->kh * d->kw;
   const int Kpad = (K + 31) / 32 * 32;
-  const long long total = (long long)Kpad * d->Cout;
-  const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
+  const long long tiles = (long long)((Kpad + 31) / 32) * ((d->Cout + 31) / 32);
+  const int grid = (int)std::min<long long>(tiles, 256 * 16);
   hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, w_packed, d->Cout, K, Kpad);
   return check_launch("pack_weight");
 }

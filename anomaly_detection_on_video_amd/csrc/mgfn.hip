@@ -329,6 +329,122 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_kernel(const float* __restric
   if (threadIdx.x == 0) { dgamma[c] = sum_dyx; dbeta[c] = sum_dy; }
 }
 
+// ---- GlanceAttention core on (C, B, T) activations, T = 32, dim_head = 64 (modeling_mgfn.py:107-123) ------------------------
+// qkv (3 * inner, B, T) [q rows, then k rows, then v rows; head h = rows h*64 .. h*64+63 of each], one workgroup per (b, h):
+//   sim[i][j] = scale * sum_d q[d][i] k[d][j];  p = softmax_j(sim);  out[d][i] = sum_j v[d][j] p[i][j]
+// p (B, heads, T, T) is kept for the backward pass.  The whole (b, h) problem (24 KB) lives in LDS; 0.26 MFLOP per workgroup:
+// latency, not arithmetic -- what matters is that torch's five launches per block (scale, bmm, softmax, bmm, copy) are one.
+constexpr int GA_T = 32, GA_D = 64;
+__global__ __launch_bounds__(256) void glance_attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ p_out,
+                                                              int inner, int heads, long long N, float scale) {
+  __shared__ float q[GA_D][GA_T + 1], k[GA_D][GA_T + 1], v[GA_D][GA_T + 1], p[GA_T][GA_T + 1];
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads, tid = threadIdx.x;
+  const long long col0 = (long long)b * GA_T;
+  for (int e = tid; e < GA_D * GA_T; e += 256) {
+    const int d = e / GA_T, t = e % GA_T;
+    const long long o = (long long)(h * GA_D + d) * N + col0 + t;
+    q[d][t] = qkv[o];
+    k[d][t] = qkv[o + (long long)inner * N];
+    v[d][t] = qkv[o + 2ll * inner * N];
+  }
+  __syncthreads();
+  // sim: thread -> row i = tid / 8, columns j = (tid % 8) * 4 .. + 3
+  const int i = tid >> 3, j0 = (tid & 7) * 4;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int d = 0; d < GA_D; ++d) {
+    const float qi = q[d][i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] += qi * k[d][j0 + e];
+  }
+  float mx = -3.4e38f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { s[e] *= scale; mx = fmaxf(mx, s[e]); }
+  // the 8 threads of a row are consecutive lanes: reduce over them
+#pragma unroll
+  for (int off = 4; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { s[e] = expf(s[e] - mx); sum += s[e]; }
+#pragma unroll
+  for (int off = 4; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float pv = s[e] * inv;
+    p[i][j0 + e] = pv;
+    p_out[((long long)blockIdx.x * GA_T + i) * GA_T + j0 + e] = pv;
+  }
+  __syncthreads();
+  // out[d][i2]: thread -> d = tid / 4, i2 = (tid % 4) * 8 .. + 7
+  const int d = tid >> 2, i0 = (tid & 3) * 8;
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+  for (int j = 0; j < GA_T; ++j) {
+    const float vj = v[d][j];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] += vj * p[i0 + e][j];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) out[(long long)(h * GA_D + d) * N + col0 + i0 + e] = o[e];
+}
+
+// backward: dqkv (3 * inner, B, T) from dout (inner, B, T), qkv and p
+__global__ __launch_bounds__(256) void glance_attn_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ qkv,
+                                                              const float* __restrict__ p_in, float* __restrict__ dqkv, int inner, int heads,
+                                                              long long N, float scale) {
+  __shared__ float q[GA_D][GA_T + 1], k[GA_D][GA_T + 1], v[GA_D][GA_T + 1], g[GA_D][GA_T + 1], p[GA_T][GA_T + 1], ds[GA_T][GA_T + 1];
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads, tid = threadIdx.x;
+  const long long col0 = (long long)b * GA_T;
+  for (int e = tid; e < GA_D * GA_T; e += 256) {
+    const int d = e / GA_T, t = e % GA_T;
+    const long long o = (long long)(h * GA_D + d) * N + col0 + t;
+    q[d][t] = qkv[o];
+    k[d][t] = qkv[o + (long long)inner * N];
+    v[d][t] = qkv[o + 2ll * inner * N];
+    g[d][t] = dout[o];
+  }
+  for (int e = tid; e < GA_T * GA_T; e += 256) p[e / GA_T][e % GA_T] = p_in[(long long)blockIdx.x * GA_T * GA_T + e];
+  __syncthreads();
+  // dp[i][j] = sum_d g[d][i] v[d][j];  dsim = p * (dp - sum_j dp p) * scale
+  const int i = tid >> 3, j0 = (tid & 7) * 4;
+  float dp[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int d = 0; d < GA_D; ++d) {
+    const float gi = g[d][i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dp[e] += gi * v[d][j0 + e];
+  }
+  float dot = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) dot += dp[e] * p[i][j0 + e];
+#pragma unroll
+  for (int off = 4; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) ds[i][j0 + e] = p[i][j0 + e] * (dp[e] - dot) * scale;
+  __syncthreads();
+  // dv[d][j] = sum_i g[d][i] p[i][j];  dq[d][i] = sum_j ds[i][j] k[d][j];  dk[d][j] = sum_i ds[i][j] q[d][i]
+  const int d = tid >> 2, t0 = (tid & 3) * 8;
+  float dv[8], dq[8], dk[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dv[e] = dq[e] = dk[e] = 0.f;
+  for (int r = 0; r < GA_T; ++r) {
+    const float gr = g[d][r], kr = k[d][r], qr = q[d][r];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      dv[e] += gr * p[r][t0 + e];    // i = r, j = t0 + e
+      dq[e] += ds[t0 + e][r] * kr;   // i = t0 + e, j = r
+      dk[e] += ds[r][t0 + e] * qr;   // i = r, j = t0 + e
+    }
+  }
+  const long long o = (long long)(h * GA_D + d) * N + col0 + t0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    dqkv[o + e] = dq[e];
+    dqkv[o + (long long)inner * N + e] = dk[e];
+    dqkv[o + 2ll * inner * N + e] = dv[e];
+  }
+}
+
 }  // namespace advhip
 
 using namespace advhip;
@@ -447,4 +563,24 @@ extern "C" int advhip_dwconv_t_bwd_f32(const float* dout, const float* v, const 
   if (K == 5) hipLaunchKernelGGL(dwconv_t_bwd_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, dout, v, w, dv, partial, H, T, per_c, chunks);
   else hipLaunchKernelGGL(dwconv_t_bwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, dout, v, w, dv, partial, H, T, per_c, chunks);
   return check_launch("dwconv_t_bwd");
+}
+
+extern "C" int advhip_glance_attention_fwd_f32(const float* qkv, float* out, float* p, int32_t heads, int64_t B, int32_t T, int32_t dim_head,
+                                               float scale, void* stream) {
+  ADVHIP_REQUIRE(qkv && out && p && heads > 0 && B > 0, "glance_attention_fwd: bad arguments");
+  ADVHIP_REQUIRE(T == GA_T && dim_head == GA_D, "glance_attention: T = %d / dim_head = %d (the kernel is built for %d / %d)", T, dim_head, GA_T, GA_D);
+  ADVHIP_REQUIRE(B * heads < (1ll << 31), "glance_attention: too many (sequence, head) pairs");
+  hipLaunchKernelGGL(glance_attn_fwd_kernel, dim3((unsigned)(B * heads)), dim3(256), 0, (hipStream_t)stream, qkv, out, p, heads * GA_D, heads,
+                     (long long)B * T, scale);
+  return check_launch("glance_attention_fwd");
+}
+
+extern "C" int advhip_glance_attention_bwd_f32(const float* dout, const float* qkv, const float* p, float* dqkv, int32_t heads, int64_t B,
+                                               int32_t T, int32_t dim_head, float scale, void* stream) {
+  ADVHIP_REQUIRE(dout && qkv && p && dqkv && heads > 0 && B > 0, "glance_attention_bwd: bad arguments");
+  ADVHIP_REQUIRE(T == GA_T && dim_head == GA_D, "glance_attention: T = %d / dim_head = %d (the kernel is built for %d / %d)", T, dim_head, GA_T, GA_D);
+  ADVHIP_REQUIRE(B * heads < (1ll << 31), "glance_attention: too many (sequence, head) pairs");
+  hipLaunchKernelGGL(glance_attn_bwd_kernel, dim3((unsigned)(B * heads)), dim3(256), 0, (hipStream_t)stream, dout, qkv, p, dqkv, heads * GA_D, heads,
+                     (long long)B * T, scale);
+  return check_launch("glance_attention_bwd");
 }

@@ -463,6 +463,42 @@ class _FocusAttnBlockCN(torch.autograd.Function):
         return dx, dg, db, dwv, per_head[:, :k].reshape(ctx.wrel_shape), per_head[:, k].contiguous(), dwo, dbo, None, None, None
 
 
+class _GlanceAttnCore(torch.autograd.Function):
+    """out = v softmax(scale q^T k)^T per (sequence, head) on (C, B, T) activations: GlanceAttention between its two 1x1 convs
+    (modeling_mgfn.py:113-122) as one launch forward, one backward (csrc/mgfn.hip: T = 32, dim_head = 64)."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, dim_head, scale):
+        _lib.require_gpu(qkv)
+        c3, b, t = qkv.shape
+        inner = c3 // 3
+        out = torch.empty((inner, b, t), device=qkv.device, dtype=torch.float32)
+        p = torch.empty((b, heads, t, t), device=qkv.device, dtype=torch.float32)
+        check(_lib.load().advhip_glance_attention_fwd_f32(ptr(qkv), ptr(out), ptr(p), heads, b, t, dim_head, C.c_float(scale), stream(qkv)),
+              "glance_attention_fwd")
+        ctx.save_for_backward(qkv, p)
+        ctx.args = (heads, dim_head, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, p = ctx.saved_tensors
+        heads, dim_head, scale = ctx.args
+        _, b, t = qkv.shape
+        dqkv = torch.empty_like(qkv)
+        check(_lib.load().advhip_glance_attention_bwd_f32(ptr(dout.contiguous()), ptr(qkv), ptr(p), ptr(dqkv), heads, b, t, dim_head, C.c_float(scale),
+                                                          stream(qkv)), "glance_attention_bwd")
+        return dqkv, None, None, None
+
+
+def glance_attention_ok(qkv: torch.Tensor, heads: int, dim_head: int) -> bool:
+    return fused_ok(qkv) and qkv.is_contiguous() and qkv.shape[2] == 32 and dim_head == 64 and qkv.shape[0] == 3 * heads * dim_head
+
+
+def glance_attention_core(qkv: torch.Tensor, heads: int, dim_head: int, scale: float) -> torch.Tensor:
+    return _GlanceAttnCore.apply(qkv, heads, dim_head, scale)
+
+
 def ffn_block_cn(x: torch.Tensor, norm, in_conv: torch.nn.Conv1d, out_conv: torch.nn.Conv1d) -> torch.Tensor:
     """x + ffn(LN(x)) with autograd (the whole step as one Function: fewer launches, no separate skip-gradient add)."""
     fresh = _will_train(in_conv.weight, in_conv.bias, out_conv.weight, out_conv.bias)

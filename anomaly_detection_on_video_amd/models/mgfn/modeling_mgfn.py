@@ -207,7 +207,10 @@ class GlanceAttention(nn.Module):
 
     def forward(self, x, residual: Optional[torch.Tensor] = None):  # (C, B, T)
         _, b, n = x.shape
-        qkv = _pointwise(self.to_qkv, self.norm(x)).view(3, self.heads, self.dim_head, b, n)
+        qkv = _pointwise(self.to_qkv, self.norm(x))
+        if mgfn_ops.glance_attention_ok(qkv, self.heads, self.dim_head):  # scale, sim, softmax, v attn^T, layout: one HIP launch
+            return _pointwise(self.to_out, mgfn_ops.glance_attention_core(qkv, self.heads, self.dim_head, self.scale), residual)
+        qkv = qkv.view(3, self.heads, self.dim_head, b, n)
         q, k, v = (t.permute(2, 0, 1, 3) for t in qkv.unbind(0))  # (b, h, d, n)
         sim = torch.matmul((q * self.scale).transpose(-1, -2), k)  # (b, h, i, j)
         out = torch.matmul(v, sim.softmax(dim=-1).transpose(-1, -2))  # (b, h, d, i)

@@ -379,6 +379,16 @@ int32_t advhip_dwconv_t_bwd_chunks(int32_t C, int64_t rows);
 int advhip_dwconv_t_bwd_f32(const float* dout, const float* v, const float* w, float* dv, float* partial, int32_t C, int32_t H,
                             int64_t rows, int32_t T, int32_t K, void* stream);
 
+/* GlanceAttention's core on (C, B, T) activations (modeling_mgfn.py:113-122: q * scale, sim = q^T k, softmax over the keys, out =
+ * v attn^T, "b h n d -> b (h d) n"), T = 32 clips, dim_head = 64: qkv (3 * heads * 64, B, T) -- the to_qkv conv's output,
+ * q rows then k rows then v rows -- -> out (heads * 64, B, T), the softmax p (B, heads, T, T) kept for the backward pass; one
+ * workgroup per (sequence, head).  Backward: dqkv from dout, qkv and p.  torch: scale + bmm + softmax + bmm + layout copy
+ * forward, ten launches backward. */
+int advhip_glance_attention_fwd_f32(const float* qkv, float* out, float* p, int32_t heads, int64_t B, int32_t T, int32_t dim_head,
+                                    float scale, void* stream);
+int advhip_glance_attention_bwd_f32(const float* dout, const float* qkv, const float* p, float* dqkv, int32_t heads, int64_t B,
+                                    int32_t T, int32_t dim_head, float scale, void* stream);
+
 /* --- MIL scorer (MGFN head) -----------------------------------------------------------------
  * Fused magnitude / score reduction of magnitude_selection_and_score_prediction
  * (src/models/mgfn/modeling_mgfn.py:314-319): for features (bs*ncrops, T, F) and per-crop scores

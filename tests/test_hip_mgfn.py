@@ -372,3 +372,27 @@ def test_unfold3_is_bit_exact(shape):
     ref = torch.stack([xp[:, :, j : j + t] for j in range(3)], dim=1).reshape(3 * c, b * t)
     got = mgfn_ops._unfold3(x.to(DEV))
     assert got.shape == ref.shape and torch.equal(got.cpu(), ref)
+
+
+@pytest.mark.parametrize("heads,b", [(1, 320), (2, 7), (3, 1)])
+def test_glance_attention_core_fwd_bwd_vs_fp64_autograd(heads, b):
+    """advhip_glance_attention_fwd/bwd_f32 (scale, q^T k, softmax over the keys, v attn^T and the "b h n d -> b (h d) n" layout
+    of GlanceAttention, modeling_mgfn.py:113-122, on (C, B, T) activations) against the same formulas in fp64 autograd."""
+    from anomaly_detection_on_video_amd import mgfn_ops
+
+    t, dh = 32, 64
+    inner = heads * dh
+    qkv = synth_tensor(f"ga.qkv{heads}{b}", (3 * inner, b, t), scale=1.5).to(DEV).requires_grad_(True)
+    g = synth_tensor(f"ga.g{heads}{b}", (inner, b, t), scale=1.0).to(DEV)
+    scale = dh ** -0.5
+    assert mgfn_ops.glance_attention_ok(qkv, heads, dh)
+    out = mgfn_ops.glance_attention_core(qkv, heads, dh, scale)
+    out.backward(g)
+    x = qkv.detach().double().cpu().requires_grad_(True)
+    q, k, v = (u.permute(2, 0, 1, 3) for u in x.view(3, heads, dh, b, t).unbind(0))  # (b, h, d, n)
+    sim = torch.matmul((q * scale).transpose(-1, -2), k)
+    ref = torch.matmul(v, sim.softmax(dim=-1).transpose(-1, -2)).permute(1, 2, 0, 3).reshape(inner, b, t)
+    ref.backward(g.double().cpu())
+    assert rel_err(out.detach().cpu(), ref.detach()) < 1e-5
+    assert rel_err(qkv.grad.cpu(), x.grad) < 1e-5
+    assert not mgfn_ops.glance_attention_ok(qkv.detach()[:, :, :31].contiguous(), heads, dh)  # other T: the torch formulation
