@@ -329,6 +329,155 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_kernel(const float* __restric
   if (threadIdx.x == 0) { dgamma[c] = sum_dyx; dbeta[c] = sum_dy; }
 }
 
+// ---- the scorer's head on the body's layout (modeling_mgfn.py:387-389: permute -> nn.LayerNorm(C) -> Linear(C, 1) -> sigmoid) ----
+// y (C, N) [the body's layout] -> xn (N, C) = (y - mean_c) * rsqrt(var_c + eps) * g + b  [the layout the MIL head reads rows of],
+// score[n] = sigmoid(xn[n, :] . w + b0).  One pass: the (C, N) -> (N, C) transposition goes through a 32 x 128 LDS tile, so both
+// the reads (along n) and the writes (along c) are coalesced; torch: a 42-MB permute copy, LayerNorm, a GEMV, a sigmoid.
+constexpr int HD_CHUNK = 128;
+__global__ __launch_bounds__(LN_THREADS) void head_ln_fc_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                    const float* __restrict__ b, const float* __restrict__ w, const float* __restrict__ b0,
+                                                                    float* __restrict__ xn, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                                    float* __restrict__ score, int Cc, long long N, float eps) {
+  __shared__ float part[2][LN_GROUPS][LN_COLS];
+  __shared__ float tile[LN_COLS][HD_CHUNK + 1];
+  const int p = threadIdx.x % LN_COLS, grp = threadIdx.x / LN_COLS;
+  const long long n0 = blockIdx.x * (long long)LN_COLS, n = n0 + p;
+  const bool ok = n < N;
+  // statistics in one read, shifted by the first channel's value (as ln_stats), nn.LayerNorm's rsqrt(var + eps)
+  const float x0 = ok ? x[n] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  if (ok)
+    for (int c = grp; c < Cc; c += LN_GROUPS) {
+      const float d = x[(long long)c * N + n] - x0;
+      s1 += d;
+      s2 += d * d;
+    }
+  part[0][grp][p] = s1;
+  part[1][grp][p] = s2;
+  __syncthreads();
+  float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+  for (int gI = 0; gI < LN_GROUPS; ++gI) { t1 += part[0][gI][p]; t2 += part[1][gI][p]; }
+  const float m1 = t1 / (float)Cc, mean = x0 + m1;
+  const float r = rsqrtf(fmaxf(t2 / (float)Cc - m1 * m1, 0.f) + eps);
+  if (ok && grp == 0) { mean_out[n] = mean; rstd_out[n] = r; }
+  float dot = 0.f;
+  for (int c0 = 0; c0 < Cc; c0 += HD_CHUNK) {
+#pragma unroll
+    for (int u = 0; u < HD_CHUNK / LN_GROUPS; ++u) {
+      const int cl = grp + LN_GROUPS * u, c = c0 + cl;
+      float v = 0.f;
+      if (ok && c < Cc) {
+        v = (x[(long long)c * N + n] - mean) * r * g[c] + b[c];
+        dot += v * w[c];
+      }
+      tile[p][cl] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < LN_COLS * HD_CHUNK; e += LN_THREADS) {
+      const int row = e / HD_CHUNK, col = e % HD_CHUNK;
+      if (n0 + row < N && c0 + col < Cc) xn[(n0 + row) * Cc + c0 + col] = tile[row][col];
+    }
+    __syncthreads();
+  }
+  part[0][grp][p] = dot;
+  __syncthreads();
+  if (ok && grp == 0) {
+    float z = b0[0];
+#pragma unroll
+    for (int gI = 0; gI < LN_GROUPS; ++gI) z += part[0][gI][p];
+    score[n] = 1.f / (1.f + expf(-z));
+  }
+}
+
+// backward: dy[n][c] = dxn[n][c] + dscore[n] s (1 - s) w[c];  dx = r (dy g - mean_c(dy g) - xhat mean_c(dy g xhat));
+// per-block partial sums [blocks][3 C + 1]: dg = sum dy xhat | db = sum dy | dw = sum dlogit xn | db0 = sum dlogit
+__global__ __launch_bounds__(LN_THREADS) void head_ln_fc_bwd_kernel(const float* __restrict__ dxn, const float* __restrict__ dscore,
+                                                                    const float* __restrict__ x, const float* __restrict__ g,
+                                                                    const float* __restrict__ b, const float* __restrict__ w,
+                                                                    const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                                    const float* __restrict__ score, float* __restrict__ dx,
+                                                                    float* __restrict__ partial, int Cc, long long N) {
+  __shared__ float part[2][LN_GROUPS][LN_COLS];
+  __shared__ float tile[LN_COLS][HD_CHUNK + 1];
+  const int p = threadIdx.x % LN_COLS, grp = threadIdx.x / LN_COLS;
+  const long long n0 = blockIdx.x * (long long)LN_COLS, n = n0 + p;
+  const bool ok = n < N;
+  const float mean = ok ? mean_in[n] : 0.f, r = ok ? rstd_in[n] : 0.f;
+  float dl = 0.f;
+  if (ok) {
+    const float sg = score[n];
+    dl = (dscore ? dscore[n] : 0.f) * sg * (1.f - sg);
+  }
+  float* prow = partial + (long long)blockIdx.x * (3 * Cc + 1);
+  auto load_tile = [&](int c0) {
+    for (int e = threadIdx.x; e < LN_COLS * HD_CHUNK; e += LN_THREADS) {
+      const int row = e / HD_CHUNK, col = e % HD_CHUNK;
+      tile[row][col] = (dxn && n0 + row < N && c0 + col < Cc) ? dxn[(n0 + row) * Cc + c0 + col] : 0.f;
+    }
+  };
+  float s1 = 0.f, s2 = 0.f;
+  for (int c0 = 0; c0 < Cc; c0 += HD_CHUNK) {
+    load_tile(c0);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < HD_CHUNK / LN_GROUPS; ++u) {
+      const int cl = grp + LN_GROUPS * u, c = c0 + cl;
+      if (c >= Cc) break;  // (uniform over the 32 lanes of a channel group)
+      float dy = 0.f, xh = 0.f, dwv = 0.f;
+      if (ok) {
+        xh = (x[(long long)c * N + n] - mean) * r;
+        dy = tile[p][cl] + dl * w[c];
+        dwv = dl * (xh * g[c] + b[c]);
+      }
+      const float dyg = dy * g[c];
+      s1 += dyg;
+      s2 += dyg * xh;
+      float a = dy * xh, bs = dy, cw = dwv;  // per-channel sums over the block's 32 positions: a half-wave reduction
+#pragma unroll
+      for (int off = LN_COLS / 2; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off, 64);
+        bs += __shfl_xor(bs, off, 64);
+        cw += __shfl_xor(cw, off, 64);
+      }
+      if (p == 0) {
+        prow[c] = a;
+        prow[Cc + c] = bs;
+        prow[2 * Cc + c] = cw;
+      }
+    }
+    __syncthreads();
+  }
+  if (grp == 0) {  // db0: sum of dlogit over the block's positions
+    float t = dl;
+#pragma unroll
+    for (int off = LN_COLS / 2; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    if (p == 0) prow[3 * Cc] = t;
+  }
+  part[0][grp][p] = s1;
+  part[1][grp][p] = s2;
+  __syncthreads();
+  float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+  for (int gI = 0; gI < LN_GROUPS; ++gI) { t1 += part[0][gI][p]; t2 += part[1][gI][p]; }
+  const float m1 = t1 / (float)Cc, m2 = t2 / (float)Cc;
+  for (int c0 = 0; c0 < Cc; c0 += HD_CHUNK) {
+    __syncthreads();
+    load_tile(c0);
+    __syncthreads();
+    if (!ok) continue;
+#pragma unroll
+    for (int u = 0; u < HD_CHUNK / LN_GROUPS; ++u) {
+      const int cl = grp + LN_GROUPS * u, c = c0 + cl;
+      if (c >= Cc) break;
+      const long long o = (long long)c * N + n;
+      const float xh = (x[o] - mean) * r;
+      const float dy = tile[p][cl] + dl * w[c];
+      dx[o] = r * (dy * g[c] - m1 - xh * m2);
+    }
+  }
+}
+
 // ---- GlanceAttention core on (C, B, T) activations, T = 32, dim_head = 64 (modeling_mgfn.py:107-123) ------------------------
 // qkv (3 * inner, B, T) [q rows, then k rows, then v rows; head h = rows h*64 .. h*64+63 of each], one workgroup per (b, h):
 //   sim[i][j] = scale * sum_d q[d][i] k[d][j];  p = softmax_j(sim);  out[d][i] = sum_j v[d][j] p[i][j]
@@ -583,4 +732,27 @@ extern "C" int advhip_glance_attention_bwd_f32(const float* dout, const float* q
   hipLaunchKernelGGL(glance_attn_bwd_kernel, dim3((unsigned)(B * heads)), dim3(256), 0, (hipStream_t)stream, dout, qkv, p, dqkv, heads * GA_D, heads,
                      (long long)B * T, scale);
   return check_launch("glance_attention_bwd");
+}
+
+extern "C" int64_t advhip_head_ln_fc_partial_rows(int64_t N) { return (N + LN_COLS - 1) / LN_COLS; }
+
+extern "C" int advhip_head_ln_fc_fwd_f32(const float* y, const float* ln_g, const float* ln_b, const float* fc_w, const float* fc_b, float* xn,
+                                         float* mean, float* rstd, float* score, int32_t C, int64_t N, float eps, void* stream) {
+  ADVHIP_REQUIRE(y && ln_g && ln_b && fc_w && fc_b && xn && mean && rstd && score && C > 0 && N > 0, "head_ln_fc_fwd: bad arguments");
+  const long long blocks = (N + LN_COLS - 1) / LN_COLS;
+  ADVHIP_REQUIRE(blocks < (1ll << 31), "head_ln_fc_fwd: too many positions");
+  hipLaunchKernelGGL(head_ln_fc_fwd_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, y, ln_g, ln_b, fc_w, fc_b, xn, mean, rstd,
+                     score, C, (long long)N, eps);
+  return check_launch("head_ln_fc_fwd");
+}
+
+extern "C" int advhip_head_ln_fc_bwd_f32(const float* d_xn, const float* d_score, const float* y, const float* ln_g, const float* ln_b,
+                                         const float* fc_w, const float* mean, const float* rstd, const float* score, float* dy, float* partial,
+                                         int32_t C, int64_t N, void* stream) {
+  ADVHIP_REQUIRE(y && ln_g && ln_b && fc_w && mean && rstd && score && dy && partial && C > 0 && N > 0, "head_ln_fc_bwd: bad arguments");
+  const long long blocks = (N + LN_COLS - 1) / LN_COLS;
+  ADVHIP_REQUIRE(blocks < (1ll << 31), "head_ln_fc_bwd: too many positions");
+  hipLaunchKernelGGL(head_ln_fc_bwd_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, d_xn, d_score, y, ln_g, ln_b, fc_w, mean,
+                     rstd, score, dy, partial, C, (long long)N);
+  return check_launch("head_ln_fc_bwd");
 }

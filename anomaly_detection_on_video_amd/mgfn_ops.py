@@ -499,6 +499,52 @@ def glance_attention_core(qkv: torch.Tensor, heads: int, dim_head: int, scale: f
     return _GlanceAttnCore.apply(qkv, heads, dim_head, scale)
 
 
+class _HeadLnFc(torch.autograd.Function):
+    """(xn, scores) = head(y): y (C, B, T) -- the body's layout -- -> xn (B, T, C) = nn.LayerNorm(C) of every position, scores
+    (B, T, 1) = sigmoid(nn.Linear(C, 1)(xn)) (modeling_mgfn.py:387-389), one launch forward and one backward: the permute that
+    torch has to materialise (42 MB at the training batch, three times per step) happens inside the kernels' LDS tiles."""
+
+    @staticmethod
+    def forward(ctx, y, ln_w, ln_b, eps, fc_w, fc_b):
+        _lib.require_gpu(y, ln_w, ln_b, fc_w, fc_b)
+        c, b, t = y.shape
+        n = b * t
+        dev = y.device
+        xn = torch.empty((b, t, c), device=dev, dtype=torch.float32)
+        mean = torch.empty((n,), device=dev, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        score = torch.empty((b, t, 1), device=dev, dtype=torch.float32)
+        check(_lib.load().advhip_head_ln_fc_fwd_f32(ptr(y), ptr(ln_w.detach()), ptr(ln_b.detach()), ptr(fc_w.detach()), ptr(fc_b.detach()), ptr(xn), ptr(mean),
+                                                    ptr(rstd), ptr(score), c, n, C.c_float(eps), stream(y)), "head_ln_fc_fwd")
+        ctx.save_for_backward(y, ln_w, ln_b, fc_w, mean, rstd, score)
+        return xn, score
+
+    @staticmethod
+    def backward(ctx, d_xn, d_score):
+        y, ln_w, ln_b, fc_w, mean, rstd, score = ctx.saved_tensors
+        c, b, t = y.shape
+        n = b * t
+        lib = _lib.load()
+        rows = lib.advhip_head_ln_fc_partial_rows(n)
+        dy = torch.empty_like(y)
+        partial = torch.empty((rows, 3 * c + 1), device=y.device, dtype=torch.float32)
+        d_xn = None if d_xn is None else d_xn.contiguous()
+        d_score = None if d_score is None else d_score.contiguous()
+        check(lib.advhip_head_ln_fc_bwd_f32(ptr(d_xn), ptr(d_score), ptr(y), ptr(ln_w.detach()), ptr(ln_b.detach()), ptr(fc_w.detach()), ptr(mean), ptr(rstd),
+                                            ptr(score), ptr(dy), ptr(partial), c, n, stream(y)), "head_ln_fc_bwd")
+        sums = partial.sum(0)
+        return dy, sums[:c], sums[c : 2 * c], None, sums[2 * c : 3 * c].view(1, c), sums[3 * c :]
+
+
+def head_ok(y: torch.Tensor, ln: torch.nn.LayerNorm, fc: torch.nn.Linear) -> bool:
+    return (fused_ok(y) and y.is_contiguous() and ln.elementwise_affine and ln.bias is not None and tuple(ln.normalized_shape) == (y.shape[0],)
+            and fc.out_features == 1 and fc.in_features == y.shape[0] and fc.bias is not None)
+
+
+def head_ln_fc(y: torch.Tensor, ln: torch.nn.LayerNorm, fc: torch.nn.Linear):
+    return _HeadLnFc.apply(y, ln.weight, ln.bias, ln.eps, fc.weight, fc.bias)
+
+
 def ffn_block_cn(x: torch.Tensor, norm, in_conv: torch.nn.Conv1d, out_conv: torch.nn.Conv1d) -> torch.Tensor:
     """x + ffn(LN(x)) with autograd (the whole step as one Function: fewer launches, no separate skip-gradient add)."""
     fresh = _will_train(in_conv.weight, in_conv.bias, out_conv.weight, out_conv.bias)

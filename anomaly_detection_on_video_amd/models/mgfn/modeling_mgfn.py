@@ -415,9 +415,13 @@ class MGFNForVideoAnomalyDetection(MGFNPreTrainedModel):
     def forward(self, video: torch.Tensor, abnormal_labels: Optional[torch.Tensor] = None,
                 normal_labels: Optional[torch.Tensor] = None) -> MGFNVideoAnomalyDetectionOutput:
         bs, ncrops = video.shape[:2]
-        x = self.backbone(video).outputs.permute(0, 2, 1)  # (bs*ncrops, T, last_dim)
-        x = self.layer_norm(x)
-        scores = self.sigmoid(self.fc(x))
+        body = self.backbone(video).outputs              # (bs*ncrops, C, T): a view of the body's (C, bs*ncrops, T) activation
+        y = body.permute(1, 0, 2)
+        if mgfn_ops.head_ok(y, self.layer_norm, self.fc):  # LayerNorm + Linear + sigmoid on the body's layout: one HIP launch
+            x, scores = mgfn_ops.head_ln_fc(y, self.layer_norm, self.fc)
+        else:
+            x = self.layer_norm(body.permute(0, 2, 1))   # (bs*ncrops, T, last_dim)
+            scores = self.sigmoid(self.fc(x))
         abn_s, nor_s, a_feat, n_feat, sc = self.magnitude_selection_and_score_prediction(x, scores, bs, ncrops)
         loss = None
         if abnormal_labels is not None and normal_labels is not None:

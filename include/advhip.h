@@ -389,6 +389,18 @@ int advhip_glance_attention_fwd_f32(const float* qkv, float* out, float* p, int3
 int advhip_glance_attention_bwd_f32(const float* dout, const float* qkv, const float* p, float* dqkv, int32_t heads, int64_t B,
                                     int32_t T, int32_t dim_head, float scale, void* stream);
 
+/* The scorer's head on the body's (C, N) layout (modeling_mgfn.py:387-389: permute -> nn.LayerNorm(C) -> nn.Linear(C, 1) -> sigmoid):
+ * xn (N, C) = LayerNorm over C of y (C, N) -- transposed through LDS, so that the MIL head reads rows --, score[n] =
+ * sigmoid(xn[n, :] . fc_w + fc_b[0]); mean / rstd (N) kept for the backward pass.  Backward: dy (C, N) from d_xn (N, C) and
+ * d_score (N) (either nullable), and partial[advhip_head_ln_fc_partial_rows(N)][3 C + 1] = per-block sums of
+ * (d ln_g | d ln_b | d fc_w | d fc_b) for the caller to add up. */
+int64_t advhip_head_ln_fc_partial_rows(int64_t N);
+int advhip_head_ln_fc_fwd_f32(const float* y, const float* ln_g, const float* ln_b, const float* fc_w, const float* fc_b, float* xn,
+                              float* mean, float* rstd, float* score, int32_t C, int64_t N, float eps, void* stream);
+int advhip_head_ln_fc_bwd_f32(const float* d_xn, const float* d_score, const float* y, const float* ln_g, const float* ln_b,
+                              const float* fc_w, const float* mean, const float* rstd, const float* score, float* dy, float* partial,
+                              int32_t C, int64_t N, void* stream);
+
 /* --- MIL scorer (MGFN head) -----------------------------------------------------------------
  * Fused magnitude / score reduction of magnitude_selection_and_score_prediction
  * (src/models/mgfn/modeling_mgfn.py:314-319): for features (bs*ncrops, T, F) and per-crop scores

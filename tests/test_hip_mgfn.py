@@ -396,3 +396,38 @@ def test_glance_attention_core_fwd_bwd_vs_fp64_autograd(heads, b):
     assert rel_err(out.detach().cpu(), ref.detach()) < 1e-5
     assert rel_err(qkv.grad.cpu(), x.grad) < 1e-5
     assert not mgfn_ops.glance_attention_ok(qkv.detach()[:, :, :31].contiguous(), heads, dh)  # other T: the torch formulation
+
+
+@pytest.mark.parametrize("c,b,t", [(1024, 320, 32), (1024, 10, 57), (96, 3, 5), (200, 2, 33)])
+def test_head_layernorm_linear_sigmoid_fwd_bwd_vs_fp64_autograd(c, b, t):
+    """advhip_head_ln_fc_fwd/bwd_f32 -- nn.LayerNorm(C) + nn.Linear(C, 1) + sigmoid on the body's (C, B, T) layout, xn written
+    (B, T, C) (modeling_mgfn.py:387-389) -- against the torch modules in fp64: both outputs, the input gradient and the four
+    parameter gradients, with gradients flowing in through xn AND through the scores."""
+    from anomaly_detection_on_video_amd import mgfn_ops
+
+    ln, fc = torch.nn.LayerNorm(c), torch.nn.Linear(c, 1)
+    with torch.no_grad():
+        ln.weight.copy_(synth_tensor(f"hd.g{c}", (c,), scale=0.25, offset=1.0))
+        ln.bias.copy_(synth_tensor(f"hd.b{c}", (c,), scale=0.1))
+        fc.weight.copy_(synth_tensor(f"hd.w{c}", (1, c), scale=float(c) ** -0.5))
+        fc.bias.copy_(synth_tensor(f"hd.b0{c}", (1,), scale=0.1))
+    y = synth_tensor(f"hd.y{c}{b}{t}", (c, b, t), scale=2.0, offset=0.3)
+    gx = synth_tensor(f"hd.gx{c}{b}{t}", (b, t, c), scale=1.0)
+    gs = synth_tensor(f"hd.gs{c}{b}{t}", (b, t, 1), scale=1.0)
+    ln64, fc64 = torch.nn.LayerNorm(c).double(), torch.nn.Linear(c, 1).double()
+    ln64.load_state_dict({k: v.double() for k, v in ln.state_dict().items()})
+    fc64.load_state_dict({k: v.double() for k, v in fc.state_dict().items()})
+    y64 = y.double().requires_grad_(True)
+    x_ref = ln64(y64.permute(1, 2, 0))
+    s_ref = torch.sigmoid(fc64(x_ref))
+    (x_ref * gx.double()).sum().add((s_ref * gs.double()).sum()).backward()
+    ln, fc = ln.to(DEV), fc.to(DEV)
+    yd = y.to(DEV).requires_grad_(True)
+    assert mgfn_ops.head_ok(yd, ln, fc)
+    xn, sc = mgfn_ops.head_ln_fc(yd, ln, fc)
+    assert xn.shape == (b, t, c) and sc.shape == (b, t, 1)
+    ((xn * gx.to(DEV)).sum() + (sc * gs.to(DEV)).sum()).backward()
+    assert rel_err(xn.detach().cpu(), x_ref.detach()) < 1e-5 and rel_err(sc.detach().cpu(), s_ref.detach()) < 1e-5
+    assert rel_err(yd.grad.cpu(), y64.grad) < 2e-5
+    for got, want in ((ln.weight.grad, ln64.weight.grad), (ln.bias.grad, ln64.bias.grad), (fc.weight.grad, fc64.weight.grad), (fc.bias.grad, fc64.bias.grad)):
+        assert rel_err(got.cpu(), want) < 2e-5

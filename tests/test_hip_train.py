@@ -30,7 +30,8 @@ def test_eval_after_fused_optimizer_steps_sees_the_new_weights(monkeypatch):
     video = mgfn_inputs(4, 32, 3).to(DEV)
     nl, al = torch.zeros(2, device=DEV), torch.ones(2, device=DEV)
     grabbed = []
-    model.fc.register_forward_hook(lambda m, i, o: grabbed.append(o.detach().cpu()))  # logits (the scores saturate)
+    # the body's output (the scores saturate; the head may run as one fused launch that never calls model.fc)
+    model.backbone.register_forward_hook(lambda m, i, o: grabbed.append(o.outputs.detach().cpu()))
 
     def logits(torch_path=False):
         model.eval()
