@@ -248,6 +248,45 @@ class ExtractScoreStream:
         return self.scorer(video=video).scores.reshape(-1)
 
 
+class HostFeeder:
+    """Pinned host buffers -> the device on a copy stream of its own, `depth` device buffers deep: the H2D transfer of step
+    k + 1 runs while step k computes instead of sitting at the head of its lane's chain.  `feed(host)` returns a `prepare`
+    callable for `ExtractScoreStream.step_async` (it makes the lane wait for the copy and hands over the device buffer);
+    `done(handle)` tells the feeder which step last read the buffer, so that the copy that re-uses it waits for that step."""
+
+    def __init__(self, device, depth: int = 4):
+        self.device, self.depth = torch.device(device), depth
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.bufs: List[Optional[torch.Tensor]] = [None] * depth
+        self.ready: List[Optional[torch.cuda.Event]] = [None] * depth
+        self.last_use: List[Optional[torch.cuda.Event]] = [None] * depth
+        self.k = 0
+
+    def feed(self, host: torch.Tensor, wrap=None):
+        j = self.k % self.depth
+        self.k += 1
+        with torch.cuda.stream(self.copy_stream):
+            if self.last_use[j] is not None:
+                self.copy_stream.wait_event(self.last_use[j])  # the step that read this buffer last has finished
+            if self.bufs[j] is None or self.bufs[j].shape != host.shape or self.bufs[j].dtype != host.dtype:
+                self.bufs[j] = torch.empty(host.shape, device=self.device, dtype=host.dtype)
+            self.bufs[j].copy_(host, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        self.ready[j] = ev
+        buf = self.bufs[j]
+
+        def prepare(_host):
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            return buf if wrap is None else wrap(buf)
+
+        prepare.slot = j
+        return prepare
+
+    def done(self, prepare, handle: "StepHandle") -> None:
+        self.last_use[prepare.slot] = handle._done
+
+
 class StepHandle:
     """Result of ExtractScoreStream.step_async: tensors produced on a lane stream."""
 

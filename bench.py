@@ -342,17 +342,30 @@ def main():
     pcie = None
     if world == 1 and not args.no_pcie and not args.h2d:
         # SURVEY 8(d) cfg 1-2: the end-to-end rate INCLUDING the host -> device copy, labelled separately (never `value`).
-        # Pinned host buffers, the copy issued on the step's lane so PCIe overlaps the other lanes' compute; 3 + K steps each.
+        # Pinned host buffers every step; the copy runs on its own stream ahead of the step that consumes it; 3 + K steps each.
         from anomaly_detection_on_video_amd.pipeline import FrameCrops
 
-        def pcie_leg(st, host, prep, batch):
+        from anomaly_detection_on_video_amd.pipeline import HostFeeder
+
+        def pcie_leg(st, host, prep, batch, wrap=None):
+            """`prep`: a prepare callable run on the step's lane (resident input: None); `wrap`: instead, feed `host` through a
+            HostFeeder (H2D on a copy stream of its own, four device buffers deep) and wrap the device buffer for the step."""
+            feeder = HostFeeder(dev) if wrap is not None else None
+
+            def one():
+                if feeder is None:
+                    st.step_async(host, prepare=prep)
+                else:
+                    p = feeder.feed(host, wrap)
+                    feeder.done(p, st.step_async(host, prepare=p))
+
             for _ in range(3):
-                st.step_async(host, prepare=prep)
+                one()
             st.drain()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(args.steps):
-                st.step_async(host, prepare=prep)
+                one()
             st.drain()
             torch.cuda.synchronize()
             return batch * args.steps / (time.perf_counter() - t1)
@@ -365,13 +378,13 @@ def main():
         stream40 = ExtractScoreStream(backbone, scorer, clips_per_video=32, ncrops=10, local_batch=40, world=1, rank=0)
         x40 = torch.randn((40, 3, 16, 224, 224), device=dev, generator=gen)
         res40 = pcie_leg(stream40, x40, None, 40)
-        frames40 = pcie_leg(stream40, fr, lambda h: FrameCrops(h.to(dev, non_blocking=True), 0, 40), 40)
+        frames40 = pcie_leg(stream40, fr, None, 40, wrap=lambda d: FrameCrops(d, 0, 40))
         del x40, stream40
         # (b) the reference's own hand-over: fp32 crop-clips from the host (extract_features.py:83-88), batch 32
         xh = x.cpu().pin_memory()
-        fp32_32 = pcie_leg(stream, xh, lambda h: h.to(dev, non_blocking=True), args.batch)
+        fp32_32 = pcie_leg(stream, xh, None, args.batch, wrap=lambda d: d)
         pcie = {
-            "note": "host buffers every step (pinned), copy on the step's lane; never the headline `value`",
+            "note": "pinned host buffers every step, H2D on a copy stream of its own four device buffers deep (pipeline.HostFeeder); never the headline `value`",
             "resized_frames_u8": {"clips_per_s": round(frames40, 2), "crop_clips_per_step": 40, "h2d_bytes_per_step": fr.numel(),
                                   "resident_same_batch_clips_per_s": round(res40, 2), "ratio_to_resident": round(frames40 / res40, 4),
                                   "input": "64 uint8 frames 256x341x3 (4 clips) -> I3Res50.forward_frames",

@@ -181,6 +181,39 @@ def test_stream_steps_from_frames_match_steps_from_crops(form):
     assert a.videos_scored == b.videos_scored == 3  # 6 steps x 2 clips = 12 clips = 3 videos of 4
 
 
+def test_host_feeder_copies_ahead_of_the_lanes_and_changes_no_result():
+    """pipeline.HostFeeder (H2D on a copy stream of its own, a ring of device buffers re-used only after the step that read them)
+    feeding a three-lane stream with DIFFERENT frames every step, ring depth 2 < lanes so that buffers are re-used while steps
+    are in flight: every step's features equal those of the same frames fed one by one on the lane itself."""
+    from anomaly_detection_on_video_amd.i3d import I3Res50
+    from anomaly_detection_on_video_amd.models.mgfn import MGFNConfig, MGFNForVideoAnomalyDetection
+    from anomaly_detection_on_video_amd.pipeline import ExtractScoreStream, FrameCrops, HostFeeder
+    from anomaly_detection_on_video_amd.weights import synth_i3d_state_dict, synth_module_state_dict
+
+    dev = _dev()
+    sc = MGFNForVideoAnomalyDetection(MGFNConfig())
+    sc.load_state_dict(synth_module_state_dict(sc))
+    sc = sc.eval().to(dev)
+    m = I3Res50()
+    m.load_state_dict(synth_i3d_state_dict())
+    m = m.eval().to(dev)
+    hosts = [torch.from_numpy(_frames(100 + i, (16, 72, 88, 3))).pin_memory() for i in range(7)]  # one clip = 10 crop-clips per step
+    a = ExtractScoreStream(m, sc, clips_per_video=4, ncrops=10, local_batch=10)
+    feeder = HostFeeder(dev, depth=2)
+    handles = []
+    for h in hosts:
+        p = feeder.feed(h, lambda d: FrameCrops(d, 0, 10, 16, 64))
+        handle = a.step_async(h, prepare=p)
+        feeder.done(p, handle)
+        handles.append(handle)
+    a.drain()
+    got = [h.result()[0].cpu() for h in handles]
+    torch.cuda.synchronize()
+    for h, g in zip(hosts, got):
+        want = m.forward_frames(h.to(dev), 0, 10, 16, 64).reshape(10, -1).cpu()
+        assert torch.equal(g, want)
+
+
 @pytest.mark.parametrize("length", [5, 8, 16])
 def test_tencrop_normalize_pass_vs_reference_golden(length):
     """mil_ops.tencrop_normalize_u8 against the reference's own GroupStandardizationTenCrop + LoopPad + permutes (goldens made
