@@ -1524,9 +1524,9 @@ struct GemmKKArgs {
   unsigned part_bytes;
 };
 
-// NS: ring depth.  2 (one k-tile in flight) where several workgroups per CU cover each other's LDS-DMA latency; deeper for
-// grids of one or two workgroups per CU (the small layers' weight gradients: few output tiles, K = 10 240), which otherwise
-// pay a memory round trip per k-tile.
+// NS: ring depth; 2 (one k-tile in flight) is what every launch uses.  A 6-deep ring for grids of one or two workgroups per CU
+// (the small layers' weight gradients: few output tiles, K = 10 240) measured no gain -- those launches are bound by the
+// latency chain of their slice sums and launch gaps, not by the ring (profiles/r03_gemm_nt_tune.txt).
 template <int BM, int BN, int NS = 2>
 __global__ __launch_bounds__(256) void gemm_kk_dma_kernel(const GemmKKArgs g) {
   constexpr int BK = 16, FM = BM / 32, FN = BN / 32;
@@ -3011,7 +3011,6 @@ static int gemm_nt_launch(const float* A, const float* B, float* C, int32_t M, i
   const dim3 grid((unsigned)blocks);
   if (tile == 3) hipLaunchKernelGGL((gemm_kk_dma_kernel<128, 128>), grid, dim3(256), 0, (hipStream_t)stream, g);
   else if (tile == 2) hipLaunchKernelGGL((gemm_kk_dma_kernel<128, 64>), grid, dim3(256), 0, (hipStream_t)stream, g);
-  else if (blocks <= 768) hipLaunchKernelGGL((gemm_kk_dma_kernel<64, 64, 6>), grid, dim3(256), 0, (hipStream_t)stream, g);  // <= 3 workgroups per CU: deep ring
   else hipLaunchKernelGGL((gemm_kk_dma_kernel<64, 64>), grid, dim3(256), 0, (hipStream_t)stream, g);
   return check_launch("gemm_nt");
 }
