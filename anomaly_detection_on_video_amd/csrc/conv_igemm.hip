@@ -1051,15 +1051,37 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   }
   // AMODE 1: lane (lane & 31) owns the 4-column group (lane & 31) * 4 of the m-tile, lane >> 5 picks the k-row of the pair
   unsigned vbase_s = OOB, vmask_s = 0;
-  const bool hsel = lane >= 32;
+  constexpr int S_RPI = 256 / BM;   // k-rows one 16-byte wave-instruction fills (BM / 4 lanes each)
+  constexpr int S_NI = 4 / S_RPI;   // such instructions per wave and k-tile (BK = 16: this wave's k-rows 4 wave .. 4 wave + 3)
+  const int rsel = lane / (BM / 4); // which of the instruction's k-rows this lane fills
+  const int rm[4] = {rsel == 0 ? -1 : 0, rsel == 1 ? -1 : 0, rsel == 2 ? -1 : 0, rsel == 3 ? -1 : 0};
   if constexpr (AMODE == 1) {
-    static_assert(AMODE == 0 || (EPI == EPI_POOL233 && BM == 128 && BK == 16 && NS == 2 && CHECK && !U8), "column-parity gather: the fused stem form");
-    const int ml4 = (lane & 31) * 4;
-    const int gt = bk_t * BRICK_T + ml4 / (BRICK_H * BRICK_W), gh = bk_h * BRICK_H + (ml4 / BRICK_W) % BRICK_H, gw = bk_w * BRICK_W + ml4 % BRICK_W;
-    if (gt < a.To && gh < a.Ho && gw < a.Wo) {  // (Wo % 4 == 0: a group is all inside or all outside)
-      const int it0 = gt * a.st - a.pt, ih0 = gh * a.sh - a.ph;
-      vbase_s = (unsigned)(bk_b * a.x_bstride + (it0 * a.H + ih0) * a.s2w_rowp + gw + a.pad_off) * 4u;
-      vmask_s = tap_bits(it0, a.kt_, a.T) | (tap_bits(ih0, a.kh_, a.H) << 10);
+    static_assert(AMODE == 0 || (BK == 16 && NS == 2 && CHECK && !U8 && (BM == 128 || BM == 64) &&
+                                 (EPI == EPI_STD || ((EPI == EPI_POOL233 || EPI == EPI_TSPAN2 || EPI == EPI_TSPAN4) && BM == 128))),
+                  "16-byte gather pieces: the fused stem (column-parity planes), the T-spanning tiles and plain tiles of (kt,1,1) convs");
+    const int ml4 = (lane % (BM / 4)) * 4;
+    if constexpr (EPI == EPI_STD) {
+      // (kt,1,1) stride-1 conv, H*W a multiple of 4: a group of 4 consecutive m is 4 consecutive positions of one plane, and
+      // tap dt reads the same 4 positions one plane on -- 16 contiguous bytes, all valid or all padding
+      const int m4 = m0 + ml4;
+      if (m4 < a.M) {
+        const int b4 = (int)a.dTHWo.div((unsigned)m4);
+        const int p4 = m4 - b4 * a.MP;
+        const int ot = (int)a.dHWo.div((unsigned)p4);
+        const int it0 = ot * a.st - a.pt;
+        vbase_s = (unsigned)(b4 * a.x_bstride + it0 * a.HW + (p4 - ot * a.HWo) + a.pad_off) * 4u;
+        vmask_s = tap_bits(it0, a.kt_, a.T) | (1u << 10) | (1u << 20);
+      }
+    } else {
+      const int gt = bk_t * BRICK_T + ml4 / (BRICK_H * BRICK_W), gh = bk_h * BRICK_H + (ml4 / BRICK_W) % BRICK_H, gw = bk_w * BRICK_W + ml4 % BRICK_W;
+      if (gt < a.To && gh < a.Ho && gw < a.Wo) {  // (Wo % 4 == 0: a group is all inside or all outside)
+        const int it0 = gt * a.st - a.pt, ih0 = gh * a.sh - a.ph;
+        vbase_s = (unsigned)(bk_b * a.x_bstride + (it0 * a.H + ih0) * a.s2w_rowp + gw + a.pad_off) * 4u;
+        vmask_s = tap_bits(it0, a.kt_, a.T) | (tap_bits(ih0, a.kh_, a.H) << 10);
+        // T-spanning tiles read the conv's own compact table, whose entries also carry the (always valid) w bit of a 1-wide
+        // kernel; a group that straddles the end of a plane reads on into the next one for positions the epilogue never stores
+        if constexpr (EPI == EPI_TSPAN2 || EPI == EPI_TSPAN4) vmask_s |= 1u << 20;
+      }
     }
   }
   const auto rx = U8 ? __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(const_cast<float*>(a.x)) - a.pad_off, 0, a.x_bytes, 0x00020000)
@@ -1107,13 +1129,22 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
     float* Bs = As + BK * BM;
     bool done16 = false;
     if constexpr (AMODE == 1) {
-      // piece g = k-rows 2 g, 2 g + 1 of the tile (this wave: rows 4 wave .. 4 wave + 3, entries ent[0..7])
+      // piece g = k-rows [g * S_RPI, (g + 1) * S_RPI) of the tile; this wave's four k-rows have their entries in ent[0..7]
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int g = wave * 2 + q;
-        const int eo = hsel ? ent[4 * q + 2] : ent[4 * q], eb = hsel ? ent[4 * q + 3] : ent[4 * q + 1];
+      for (int q = 0; q < S_NI; ++q) {
+        const int g = wave * S_NI + q;
+        int eo, eb;
+        if constexpr (S_RPI == 2) {
+          eo = rsel ? ent[4 * q + 2] : ent[4 * q];
+          eb = rsel ? ent[4 * q + 3] : ent[4 * q + 1];
+        } else {
+          // four-way pick by per-lane masks (set once, outside the loop): a `rsel == i ? ent[..]` chain makes hipcc index a
+          // stack copy of the entries -- scratch loads inside the k loop, which also count against the ring's vmcnt waits
+          eo = (ent[0] & rm[0]) | (ent[2] & rm[1]) | (ent[4] & rm[2]) | (ent[6] & rm[3]);
+          eb = (ent[1] & rm[0]) | (ent[3] & rm[1]) | (ent[5] & rm[2]) | (ent[7] & rm[3]);
+        }
         const unsigned voff = ((vmask_s & (unsigned)eb) == (unsigned)eb) ? vbase_s + (unsigned)eo : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(As + g * 2 * BM), A16_BYTES, voff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(As + g * S_RPI * BM), A16_BYTES, voff, 0, 0, 0);
       }
       done16 = true;
     }
@@ -2318,6 +2349,24 @@ static SplitLayout split_layout(const advhip_conv3d_desc* d, const Geometry& g, 
 
 namespace advhip {
 static void set_bricks(ConvArgs& a, int nbt, int nbh, int nbw);  // defined with the pooling launchers below
+
+// the 2-deep-ring LDS-DMA kernel of a tile: unchecked (1x1x1, no padding), 16-byte gather pieces ((kt,1,1) stride-1 convs on
+// planes of a multiple of 4 positions, 16-deep k-tiles), or the 4-byte gather
+template <int BM_, int BN_, int BK_>
+static void launch_dma2(bool nocheck, bool s16, dim3 grid, hipStream_t st, const ConvArgs& a) {
+  if (nocheck) {
+    hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, false, 2>), grid, dim3(256), 0, st, a);
+    return;
+  }
+  if constexpr (BK_ == 16) {
+    if (s16) {
+      hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, true, 2, EPI_STD, false, 1>), grid, dim3(256), 0, st, a);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, true, 2>), grid, dim3(256), 0, st, a);
+}
+
 }
 
 extern "C" int64_t advhip_conv3d_workspace_bytes(const advhip_conv3d_desc* d) {
@@ -2475,6 +2524,12 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
     a.kh_ = 1; a.kw_ = 1;
     set_bricks(a, g.To / tspan_bt, 1, (a.Wo + 128 / tspan_bt - 1) / (128 / tspan_bt));
     a.Tp = 0;
+    // 16-byte gather pieces: a tile row segment is BW consecutive positions of one flattened plane, tap dt of a k-row reads
+    // the same segment one plane on -- four consecutive positions are four consecutive floats (at a 4-byte aligned address:
+    // LDS-DMA takes it, tools/probe/), so a lane fetches a 4-position group and a wave-instruction two whole k-rows, offsets
+    // from the conv's own compact table {(ci*T + dt)*HW*4, tap bits}
+    a.ktab_s2w = reinterpret_cast<const int2*>(a.ktab + g.Kpad);
+    a.s2w_rowp = a.W;
   }
   dim3 grid((unsigned)(a.tiles_m * a.tiles_n * c.splits));
   hipStream_t st = (hipStream_t)stream;
@@ -2484,6 +2539,11 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
   // BK = 32 needs Kpad % 32 == 0: the packed weights are padded to 16 rows only, but the k-table
   // marks rows >= K invalid and the weight rows read beyond Kpad must exist -> require it.
   if (BK == 32) ADVHIP_REQUIRE(g.Kpad % 32 == 0, "conv3d: BK=32 variants need K padded to 32 (K=%d)", g.K);
+  // (kt,1,1) stride-1 conv whose planes are a multiple of 4 positions long: a group of 4 consecutive m is 16 contiguous bytes for
+  // every tap (all inside or all padding) -- 16-byte gather pieces, offsets from the conv's own compact table
+  const bool s16 = !nocheck && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 && a.HW % 4 == 0 &&
+                   d->kt <= 10 && g.K % 4 == 0;
+  if (s16) a.ktab_s2w = reinterpret_cast<const int2*>(a.ktab + g.Kpad);
   // ... and rows of 4 consecutive positions contiguous and 16-byte aligned in x: 16-byte LDS-DMA pieces for A
   a.a16 = (a16pad || (nocheck && d->st == 1 && d->sh == 1 && d->sw == 1 && a.THW % 4 == 0 && xbs % 4 == 0 && ((uintptr_t)x & 15) == 0)) ? 1 : 0;
 #define ADVHIP_FAST_CASE(ID, BM_, BN_, BK_)                                                                         \
@@ -2501,10 +2561,9 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
     if (nocheck) hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, false, 4>), grid, dim3(256), 0, st, a);  \
     else hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, true, 4>), grid, dim3(256), 0, st, a);           \
     break;
-#define ADVHIP_DMA2_CASE(ID, BM_, BN_, BK_)                                                                          \
-  case ADVHIP_ALGO_DMA2_BASE + ID:                                                                                   \
-    if (nocheck) hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, false, 2>), grid, dim3(256), 0, st, a);  \
-    else hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, true, 2>), grid, dim3(256), 0, st, a);           \
+#define ADVHIP_DMA2_CASE(ID, BM_, BN_, BK_)                                   \
+  case ADVHIP_ALGO_DMA2_BASE + ID:                                            \
+    launch_dma2<BM_, BN_, BK_>(nocheck, s16, grid, st, a);                    \
     break;
 #define ADVHIP_BF16X3_CASE(ID, BN_)                                                                               \
   case ADVHIP_ALGO_BF16X3_BASE + ID:                                                                               \
@@ -2513,8 +2572,8 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
     break;
   switch (c.algo) {
     case ADVHIP_ALGO_TSPAN_128x64:
-      if (tspan_bt == 4) hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, true, 2, EPI_TSPAN4>), grid, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, true, 2, EPI_TSPAN2>), grid, dim3(256), 0, st, a);
+      if (tspan_bt == 4) hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, true, 2, EPI_TSPAN4, false, 1>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, true, 2, EPI_TSPAN2, false, 1>), grid, dim3(256), 0, st, a);
       break;
     ADVHIP_DMA2_CASE(ADVHIP_ALGO_IGEMM_128x128, 128, 128, 16)
     ADVHIP_DMA2_CASE(ADVHIP_ALGO_IGEMM_128x64, 128, 64, 16)
