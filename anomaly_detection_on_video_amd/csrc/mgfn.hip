@@ -199,8 +199,8 @@ __global__ __launch_bounds__(256) void dwconv_t_fwd_kernel(const float* __restri
   }
 }
 
-// dv[c, b, t] = sum_j w[h][j] * dout[c, b, t - j + K/2];  per block (one channel c, a chunk of its B*T elements):
-// partial[blk][0..K-1] = sum dout[c,b,t] * v[c,b,t+j-K/2],  partial[blk][K] = sum dout
+// dv[c, b, t] = sum_j w[h][j] * dout[c, b, t - j + K/2];  per block (one channel c = c_idx * H + h, a chunk of its B*T elements):
+// partial[c_idx * chunks + chunk][h][0..K-1] = sum dout[c,b,t] * v[c,b,t+j-K/2],  [..][h][K] = sum dout
 template <int K>
 __global__ __launch_bounds__(256) void dwconv_t_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ v,
                                                            const float* __restrict__ w, float* __restrict__ dv,
@@ -236,7 +236,9 @@ __global__ __launch_bounds__(256) void dwconv_t_bwd_kernel(const float* __restri
     if (lane == 0) red[wv][j] = a;
   }
   __syncthreads();
-  if (threadIdx.x <= K) partial[(long long)blockIdx.x * (K + 1) + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  // partial[(c / H) * chunks + chunk][h][K + 1]: the rows of one head's column block are what the caller adds up (advhip_colsum_f32)
+  if (threadIdx.x <= K)
+    partial[(((long long)(c / H) * chunks + chunk) * H + h) * (K + 1) + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 // The rows a k = 3, padding 1 temporal conv contracts with, for its weight gradient dW = dY . U^T:
@@ -327,6 +329,36 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_kernel(const float* __restric
   const float* ar = add ? add + (long long)c * N : nullptr;
   for (long long i = threadIdx.x; i < N; i += 256) o[i] = k * (dr[i] - m1 - (xr[i] - mu) * rstd * m2) + (ar ? ar[i] : 0.f);
   if (threadIdx.x == 0) { dgamma[c] = sum_dyx; dbeta[c] = sum_dy; }
+}
+
+// dst[c] = sum over r (in row order) of src[r][c] for a (rows, cols) matrix of per-block partial sums (LayerNorm dg | db, the head's
+// four parameter gradients, the depth-wise conv's filter gradients): 32 columns x 8 row groups per block, each thread walks its
+// rows eight loads at a time, the row groups are added in fixed order through LDS.  torch's generic reduction takes 10-20 us on
+// these few-hundred-row matrices; 26 of them per training step.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ src, float* __restrict__ dst, long long rows, int cols) {
+  __shared__ float part[8][33];
+  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float acc = 0.f;
+  if (c < cols) {
+    long long r = grp;
+    for (; r + 56 < rows; r += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(r + 8 * u) * cols + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; r < rows; r += 8) acc += src[r * cols + c];
+  }
+  part[grp][cl] = acc;
+  __syncthreads();
+  if (grp == 0 && c < cols) {
+    float t = part[0][cl];
+#pragma unroll
+    for (int gI = 1; gI < 8; ++gI) t += part[gI][cl];
+    dst[c] = t;
+  }
 }
 
 // ---- the scorer's head on the body's layout (modeling_mgfn.py:387-389: permute -> nn.LayerNorm(C) -> Linear(C, 1) -> sigmoid) ----
@@ -755,4 +787,10 @@ extern "C" int advhip_head_ln_fc_bwd_f32(const float* d_xn, const float* d_score
   hipLaunchKernelGGL(head_ln_fc_bwd_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, d_xn, d_score, y, ln_g, ln_b, fc_w, mean,
                      rstd, score, dy, partial, C, (long long)N);
   return check_launch("head_ln_fc_bwd");
+}
+
+extern "C" int advhip_colsum_f32(const float* src, float* dst, int64_t rows, int32_t cols, void* stream) {
+  ADVHIP_REQUIRE(src && dst && rows > 0 && cols > 0, "colsum: bad arguments");
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((cols + 31) / 32)), dim3(256), 0, (hipStream_t)stream, src, dst, (long long)rows, cols);
+  return check_launch("colsum");
 }

@@ -177,6 +177,14 @@ def conv_cn(x: torch.Tensor, w_packed: torch.Tensor, cout: int, k: int = 1, shif
     return (y, z) if want_preact else y
 
 
+def colsum(partial: torch.Tensor) -> torch.Tensor:
+    """(rows, cols) per-block partial sums -> (cols,), rows added in order (include/advhip.h: advhip_colsum_f32)."""
+    rows, cols = partial.shape
+    out = torch.empty((cols,), device=partial.device, dtype=torch.float32)
+    check(_lib.load().advhip_colsum_f32(ptr(partial), ptr(out), rows, cols, stream(partial)), "colsum")
+    return out
+
+
 def chan_stats(x: torch.Tensor, eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
     """(mean, 1 / (std_biased + eps)) over the channels of a contiguous (C, B, T) activation, per position."""
     _lib.require_gpu(x)
@@ -401,8 +409,19 @@ class _FFNBlockCN(torch.autograd.Function):
         pgb = torch.empty((rows, 2 * dim), device=x.device, dtype=torch.float32)
         check(lib.advhip_chan_layernorm_bwd_add_f32(ptr(dxh), ptr(x), ptr(gf), ptr(mu), ptr(rs), ptr(dy), ptr(dx), ptr(pgb), dim, n,
                                                     C.c_float(ctx.eps), stream(x)), "chan_layernorm_bwd_add")
-        sums = pgb.sum(0)
+        sums = colsum(pgb)
         return dx, sums[:dim].reshape(ctx.gshape), sums[dim:].reshape(ctx.gshape), None, dw1, db1, dw2, db2, None
+
+
+PENDING_COUNTERS: list = []  # BatchNorm1d.num_batches_tracked tensors whose += 1 is still owed
+
+
+def flush_counters() -> None:
+    """num_batches_tracked += 1 for every BatchNorm layer that ran through _FocusAttnBlockCN since the last call: one
+    multi-tensor launch instead of one per layer (MGFNModel.forward calls this after the body)."""
+    if PENDING_COUNTERS:
+        torch._foreach_add_(PENDING_COUNTERS, 1)
+        PENDING_COUNTERS.clear()
 
 
 class _FocusAttnBlockCN(torch.autograd.Function):
@@ -426,7 +445,7 @@ class _FocusAttnBlockCN(torch.autograd.Function):
                                                  ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
                                                  C.c_float(bn.momentum if track else 0.0), c, n, C.c_float(bn.eps), stream(x)), "bn_rows_fwd_running")
         if track:
-            bn.num_batches_tracked += 1
+            PENDING_COUNTERS.append(bn.num_batches_tracked)  # += 1 for all the body's BatchNorm layers in one launch (flush_counters)
         v = conv_cn(xb, pack_kc_cached(wv, fresh), inner, 1)
         k = wrel.shape[-1]
         w2 = wrel.detach().reshape(heads, k).contiguous()
@@ -452,7 +471,7 @@ class _FocusAttnBlockCN(torch.autograd.Function):
         dv = torch.empty_like(v)
         partial = torch.empty((inner * chunks, k + 1), device=x.device, dtype=torch.float32)
         check(lib.advhip_dwconv_t_bwd_f32(ptr(do), ptr(v), ptr(w2), ptr(dv), ptr(partial), inner, heads, b_, t, k, stream(x)), "dwconv_t_bwd")
-        per_head = partial.view(inner // heads, heads, chunks, k + 1).sum(dim=(0, 2))  # channel = c_idx * H + h_idx
+        per_head = colsum(partial.view(inner // heads * chunks, heads * (k + 1))).view(heads, k + 1)  # rows = (c_idx, chunk)
         dwv, _ = _dw_db(dv, xb, need[3], False)
         dxb = conv_cn(dv, wv.detach().view(inner, c), c, 1)
         dx = torch.empty_like(x)
@@ -532,7 +551,7 @@ class _HeadLnFc(torch.autograd.Function):
         d_score = None if d_score is None else d_score.contiguous()
         check(lib.advhip_head_ln_fc_bwd_f32(ptr(d_xn), ptr(d_score), ptr(y), ptr(ln_w.detach()), ptr(ln_b.detach()), ptr(fc_w.detach()), ptr(mean), ptr(rstd),
                                             ptr(score), ptr(dy), ptr(partial), c, n, stream(y)), "head_ln_fc_bwd")
-        sums = partial.sum(0)
+        sums = colsum(partial)
         return dy, sums[:c], sums[c : 2 * c], None, sums[2 * c : 3 * c].view(1, c), sums[3 * c :]
 
 
@@ -635,7 +654,7 @@ class _ChanLayerNorm(torch.autograd.Function):
         pb = torch.empty_like(pg)
         check(lib.advhip_chan_layernorm_bwd_f32(ptr(dy), ptr(x), ptr(gf), ptr(mu), ptr(rs), ptr(dx), ptr(pg), ptr(pb), c, n,
                                                 C.c_float(ctx.eps), stream(x)), "chan_layernorm_bwd")
-        return dx, pg.sum(0).view(ctx.gshape), pb.sum(0).view(ctx.gshape), None
+        return dx, colsum(pg).view(ctx.gshape), colsum(pb).view(ctx.gshape), None
 
 
 class _DWConvT(torch.autograd.Function):
@@ -664,7 +683,7 @@ class _DWConvT(torch.autograd.Function):
         dv = torch.empty_like(v)
         partial = torch.empty((c * chunks, k + 1), device=v.device, dtype=torch.float32)
         check(lib.advhip_dwconv_t_bwd_f32(ptr(dout), ptr(v), ptr(w2), ptr(dv), ptr(partial), c, h, b, t, k, stream(v)), "dwconv_t_bwd")
-        per_head = partial.view(c // h, h, chunks, k + 1).sum(dim=(0, 2))  # channel = c_idx * H + h_idx
+        per_head = colsum(partial.view(c // h * chunks, h * (k + 1))).view(h, k + 1)  # rows = (c_idx, chunk), channel = c_idx * H + h_idx
         return dv, per_head[:, :k].reshape(ctx.wshape), per_head[:, k].contiguous()
 
 

@@ -89,6 +89,65 @@ class _MilTopkSelect(torch.autograd.Function):
         return None, None, d_sc, d_feat, None, None
 
 
+class _MilTopkSelectSplit(torch.autograd.Function):
+    """mil_topk_select of the normal half (videos [0, h)) and of the abnormal half (videos [h, 2h)) of one batch
+    (modeling_mgfn.py:324-332, 364-372) as ONE autograd node: the two halves' feature gradients are scattered into one
+    zero-filled (bs*ncrops, T, F) buffer -- two separate nodes on slices of `features` make autograd zero-fill and add two
+    full-size tensors (five launches over 42 MB at the training batch)."""
+
+    @staticmethod
+    def forward(ctx, mag, keep_a, keep_n, sc, features, ncrops: int, k: int):
+        mag, sc, features = mag.contiguous(), sc.contiguous(), features.contiguous()
+        require_gpu(mag, keep_a, keep_n, sc, features)
+        bs, T = mag.shape
+        rows, T2, F = features.shape
+        h = bs // 2
+        if bs != 2 * h or rows != bs * ncrops or T2 != T or sc.shape != mag.shape:
+            raise ValueError("mil_topk_select_split: inconsistent shapes")
+        dev = mag.device
+        lib = _lib.load()
+        outs = []
+        for half, keep in ((1, keep_a), (0, keep_n)):  # abnormal first, as the reference calls them
+            keep = None if keep is None else keep.contiguous()
+            if keep is not None and tuple(keep.shape) != (h, T):
+                raise ValueError("mil_topk_select_split: keep mask must be (bs/2, T)")
+            idx = torch.empty((h, k), device=dev, dtype=torch.int64)
+            sel = torch.empty((ncrops * h, k, F), device=dev, dtype=torch.float32)
+            score = torch.empty((h,), device=dev, dtype=torch.float32)
+            lo = half * h
+            check(lib.advhip_mil_topk_select_f32(ptr(mag[lo : lo + h]), ptr(keep), ptr(sc[lo : lo + h]), ptr(features[lo * ncrops : (lo + h) * ncrops]),
+                                                 ptr(idx), ptr(sel), ptr(score), h, ncrops, T, F, k, stream()), "mil_topk_select")
+            outs += [idx, sel, score.view(h, 1)]
+        ctx.save_for_backward(outs[0], outs[3])
+        ctx.dims = (h, ncrops, T, F, k)
+        ctx.mark_non_differentiable(outs[0], outs[3])
+        return tuple(outs)  # idx_a, sel_a, score_a, idx_n, sel_n, score_n
+
+    @staticmethod
+    def backward(ctx, _dia, d_sel_a, d_score_a, _din, d_sel_n, d_score_n):
+        idx_a, idx_n = ctx.saved_tensors
+        h, ncrops, T, F, k = ctx.dims
+        dev = idx_a.device
+        want_f, want_s = ctx.needs_input_grad[4], ctx.needs_input_grad[3]
+        d_feat = torch.zeros((2 * h * ncrops, T, F), device=dev, dtype=torch.float32) if want_f else None
+        d_sc = torch.zeros((2 * h, T), device=dev, dtype=torch.float32) if want_s else None
+        lib = _lib.load()
+        for half, idx, d_sel, d_score in ((1, idx_a, d_sel_a, d_score_a), (0, idx_n, d_sel_n, d_score_n)):
+            ds = d_sel.contiguous() if (d_sel is not None and want_f) else None
+            dscore = d_score.contiguous() if (d_score is not None and want_s) else None
+            if ds is None and dscore is None:
+                continue
+            lo = half * h
+            check(lib.advhip_mil_topk_select_bwd_f32(ptr(idx), ptr(ds), ptr(dscore), ptr(d_feat[lo * ncrops : (lo + h) * ncrops]) if want_f else None,
+                                                     ptr(d_sc[lo : lo + h]) if want_s else None, h, ncrops, T, F, k, stream()), "mil_topk_select_bwd")
+        return None, None, None, d_sc, d_feat, None, None
+
+
+def mil_topk_select_split(mag, keep_a: Optional[torch.Tensor], keep_n: Optional[torch.Tensor], sc, features, ncrops: int, k: int):
+    """-> (idx_a, sel_a, score_a, idx_n, sel_n, score_n): videos [bs/2, bs) are the abnormal half, [0, bs/2) the normal one."""
+    return _MilTopkSelectSplit.apply(mag, keep_a, keep_n, sc, features, ncrops, k)
+
+
 class _MgfnLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sc, abn_score, nor_score, a_feat, n_feat, abn_labels, nor_labels, ncrops: int):

@@ -359,7 +359,9 @@ class MGFNModel(MGFNPreTrainedModel):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             mgfn_ops.invalidate_caches()  # the weights are about to be updated: no cached packed copy may outlive this pass
         # internal layout (C, B, T); `outputs` is returned in the reference's (B, C, T) shape (a view)
-        return MGFNModelOutput(outputs=self.layers(self.amplifier(x)).permute(1, 0, 2))
+        y = self.layers(self.amplifier(x))
+        mgfn_ops.flush_counters()  # (the BatchNorm layers' num_batches_tracked += 1, all in one launch)
+        return MGFNModelOutput(outputs=y.permute(1, 0, 2))
 
 
 class MGFNForVideoAnomalyDetection(MGFNPreTrainedModel):
@@ -390,25 +392,31 @@ class MGFNForVideoAnomalyDetection(MGFNPreTrainedModel):
     def magnitude_selection_and_score_prediction(self, features, scores, batch_size, ncrops):
         """HIP restatement of modeling_mgfn.py:302-374; features (bs*ncrops,T,F), scores (bs*ncrops,T,1)."""
         mag, sc = mil_ops.mil_magnitude(features, scores.squeeze(-1), batch_size, ncrops)
-        if self.force_split or self.training:
-            h = batch_size // 2
-            nf, af = features[: h * ncrops], features[h * ncrops :]
-            nm, am = mag[:h], mag[h:]
-            ns, as_ = sc[:h], sc[h:]
-        else:
-            nf = af = features
-            nm = am = mag
-            ns = as_ = sc
+        split = self.force_split or self.training
         if self.injected_keep is not None:
             keep_a, keep_n = self.injected_keep
         elif self.training:
             # same call order as the reference: abnormal first, then normal (modeling_mgfn.py:364-372)
-            keep_a = self.dropout(torch.ones_like(am))
-            keep_n = self.dropout(torch.ones_like(nm))
+            h = batch_size // 2 if split else batch_size
+            keep_a = self.dropout(torch.ones((h, mag.shape[1]), device=mag.device, dtype=mag.dtype))
+            keep_n = self.dropout(torch.ones((h, mag.shape[1]), device=mag.device, dtype=mag.dtype))
         else:
             keep_a = keep_n = None
-        idx_a, feat_a, score_a = mil_ops.mil_topk_select(am, keep_a, as_, af, ncrops, self.k)
-        idx_n, feat_n, score_n = mil_ops.mil_topk_select(nm, keep_n, ns, nf, ncrops, self.k)
+        if split and batch_size % 2 == 0:
+            # both halves as one autograd node (one zero-filled feature-gradient buffer instead of two padded and added ones)
+            idx_a, feat_a, score_a, idx_n, feat_n, score_n = mil_ops.mil_topk_select_split(mag, keep_a, keep_n, sc, features, ncrops, self.k)
+        else:
+            if split:
+                h = batch_size // 2
+                nf, af = features[: h * ncrops], features[h * ncrops :]
+                nm, am = mag[:h], mag[h:]
+                ns, as_ = sc[:h], sc[h:]
+            else:
+                nf = af = features
+                nm = am = mag
+                ns = as_ = sc
+            idx_a, feat_a, score_a = mil_ops.mil_topk_select(am, keep_a, as_, af, ncrops, self.k)
+            idx_n, feat_n, score_n = mil_ops.mil_topk_select(nm, keep_n, ns, nf, ncrops, self.k)
         self.last_indices = (idx_a, idx_n)
         return score_a, score_n, feat_a, feat_n, sc.unsqueeze(2)
 

@@ -363,6 +363,10 @@ int advhip_chan_layernorm_bwd_add_f32(const float* dy, const float* x, const flo
  * transpose + pack. */
 int advhip_conv1d_pack_weight_dx_f32(const float* w, float* w_packed, int32_t Cout, int32_t Cin, int32_t k, void* stream);
 
+/* dst[c] = sum over r, in row order, of src[r][c]: the per-block partial sums the backward kernels above leave to the caller
+ * (rows = a few hundred blocks). */
+int advhip_colsum_f32(const float* src, float* dst, int64_t rows, int32_t cols, void* stream);
+
 /* The operand of a k = 3, padding 1 Conv1d's weight gradient (autograd of nn.Conv1d, modeling_mgfn.py:101,155):
  * u[(c*3 + j), r, t] = x[c, r, t + j - 1] (zero outside [0, T)), x (C, rows, T) -> u (3C, rows, T); dW = dY . u^T by
  * advhip_gemm_nt_f32.  T a multiple of 4. */
@@ -373,8 +377,8 @@ int advhip_unfold3_f32(const float* x, float* u, int32_t C, int64_t rows, int32_
  * (zero padding).  K in {3, 5}. */
 int advhip_dwconv_t_fwd_f32(const float* v, const float* w, const float* bias, float* out, int32_t C, int32_t H, int64_t rows,
                             int32_t T, int32_t K, void* stream);
-/* Backward: dv, and partial[C * chunks][K + 1] = per-block sums of (dout * v shifted by tap j, j < K; dout) -- the caller
- * adds the blocks of every channel of a head (chunks = advhip_dwconv_t_bwd_chunks(C, rows)). */
+/* Backward: dv, and partial[(C / H) * chunks][H][K + 1] = per-block sums of (dout * v shifted by tap j, j < K; dout) of channel
+ * c = c_idx * H + h -- the caller adds the (C / H) * chunks rows (advhip_colsum_f32; chunks = advhip_dwconv_t_bwd_chunks(C, rows)). */
 int32_t advhip_dwconv_t_bwd_chunks(int32_t C, int64_t rows);
 int advhip_dwconv_t_bwd_f32(const float* dout, const float* v, const float* w, float* dv, float* partial, int32_t C, int32_t H,
                             int64_t rows, int32_t T, int32_t K, void* stream);
