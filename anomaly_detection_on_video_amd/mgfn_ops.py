@@ -280,15 +280,30 @@ class _Fork:
         return False
 
 
+# k = 3 layers as plain GEMMs on unfolded operands (K3_AS_GEMM): the im2col-free k = 3 conv gathers 4-byte pieces (its taps shift
+# positions inside a row of T, with zero padding at the row ends, so 16-byte pieces are out) and runs 110-116 TFLOP/s; the
+# same contraction as a 1x1 GEMM over U = unfold3(x) (3 Cin rows, one 126-MB pass at stage 2) takes the 16-byte operand path at
+# ~140 TFLOP/s, and U is what the weight gradient contracts with anyway (kept for the backward pass instead of x).
+K3_AS_GEMM = os.environ.get("ADV_MGFN_K3_GEMM", "1") == "1"
+
+
 class _LinearCN(torch.autograd.Function):
     """y = conv1d_k(x; W) + b (+ residual), k in {1, 3}, no activation."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, fresh):
         cout, cin, k = weight.shape
-        y = conv_cn(x, pack_kc_cached(weight, fresh), cout, k, shift=bias.detach() if bias is not None else None,
-                    residual=residual.detach().contiguous() if residual is not None else None)
-        ctx.save_for_backward(x, weight)
+        shift = bias.detach() if bias is not None else None
+        res = residual.detach().contiguous() if residual is not None else None
+        unfolded = K3_AS_GEMM and k == 3 and x.shape[2] % 4 == 0 and any(ctx.needs_input_grad)
+        if unfolded:  # W viewed (Cout, 3 Cin) times U[(c*3 + j), n] = x[c, n + j - 1]: the packed operand is the k = 3 one
+            u = _unfold3(x).view(3 * cin, x.shape[1], x.shape[2])
+            y = conv_cn(u, pack_kc_cached(weight, fresh), cout, 1, shift=shift, residual=res)
+            ctx.save_for_backward(u, weight)
+        else:
+            y = conv_cn(x, pack_kc_cached(weight, fresh), cout, k, shift=shift, residual=res)
+            ctx.save_for_backward(x, weight)
+        ctx.unfolded = unfolded
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         # y = conv(x) + x (the blocks' `x = scc(x) + x`): dL/dx = conv^T(dy) + dy comes out of ONE launch (dy as the dX GEMM's
         # residual) instead of a GEMM, a pass-through and autograd's add over the whole activation
@@ -297,7 +312,7 @@ class _LinearCN(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight = ctx.saved_tensors  # (x is U = unfold3(x) when ctx.unfolded)
         cout, cin, k = weight.shape
         dy = dy.contiguous()
         dx = dw = db = None
@@ -305,12 +320,18 @@ class _LinearCN(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if k == 1:  # dX = W^T dY: the parameter's own (o, c) layout IS the kernels' [K = o][Cout = c] operand
                 dx = conv_cn(dy, weight.detach().view(cout, cin), cin, 1, residual=dy if fold else None)
+            elif ctx.unfolded:  # transposed conv as a GEMM over unfold3(dY): rows (o*3 + j') = dY[o, n + j' - 1] against pack_dx's
+                ud = _unfold3(dy).view(3 * cout, dy.shape[1], dy.shape[2])  # [(o*3 + j')][c] = W[o][c][2 - j']
+                dx = conv_cn(ud, pack_dx(weight.detach()), cin, 1, residual=dy if fold else None)
             else:       # transposed conv: W'[c][o][j] = W[o][c][k-1-j], packed straight from the parameter (one launch)
                 dx = conv_cn(dy, pack_dx(weight.detach()), cin, k, residual=dy if fold else None)
         with _Fork(dy, x) as fk:
             want_db = ctx.has_bias and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:  # dW = dY X^T, and db = rowsum(dY) out of the same launch
-                xk = x.detach().view(cin, -1) if k == 1 else _unfold3(x.detach())
+                if k == 1:
+                    xk = x.detach().view(cin, -1)
+                else:
+                    xk = x.view(3 * cin, -1) if ctx.unfolded else _unfold3(x.detach())
                 res = ops.gemm_nt(dy.view(cout, -1), xk, rowsum=want_db)
                 dw, db = res if want_db else (res, None)
                 dw = dw.view(cout, cin, k)
