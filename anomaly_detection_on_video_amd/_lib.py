@@ -137,6 +137,8 @@ SIGNATURES = {
     "advhip_chan_layernorm_bwd_add_f32": (C.c_int, [_P] * 8 + [_I, _L, C.c_float, _P]),
     "advhip_conv1d_pack_weight_dx_f32": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "advhip_colsum_f32": (C.c_int, [_P, _P, _L, _I, _P]),
+    "advhip_pack_item_tiles": (C.c_int64, [_I, _I, _I, _I]),
+    "advhip_pack_weights_multi_f32": (C.c_int, [_P, _I, _I, _P]),
     "advhip_unfold3_f32": (C.c_int, [_P, _P, _I, _L, _I, _P]),
     "advhip_dwconv_t_fwd_f32": (C.c_int, [_P] * 4 + [_I, _I, _L, _I, _I, _P]),
     "advhip_dwconv_t_bwd_chunks": (_I, [_I, _L]),

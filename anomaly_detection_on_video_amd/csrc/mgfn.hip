@@ -626,6 +626,49 @@ __global__ __launch_bounds__(256) void glance_attn_bwd_kernel(const float* __res
   }
 }
 
+
+// ---- every GEMM weight of a training step re-packed in ONE launch -------------------------------------------------------
+// A differentiated forward needs the packed image of each (just updated) parameter: 42 forward operands and 8 transposed-conv
+// operands at the benchmarked size, 5 us launches each.  Block t takes 32 x 32 output tile t of the item whose tile range holds
+// it: mode 0 = pack_weight_kernel's LDS transpose, mode 1 = pack_weight_dx_kernel's flipped gather.
+__global__ __launch_bounds__(256) void pack_multi_kernel(const advhip_pack_item* __restrict__ items, int n_items, int n_tiles) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    int lo = 0, hi = n_items - 1;  // the last item whose first tile is <= t
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (items[mid].tile_begin <= t) lo = mid; else hi = mid - 1;
+    }
+    const advhip_pack_item it = items[lo];
+    const int lt = t - it.tile_begin;
+    if (it.mode == 0) {
+      const int K = it.Cin * it.k, Kpad = (K + 31) / 32 * 32, tiles_k = Kpad / 32;
+      const int k0 = (lt % tiles_k) * 32, c0 = (lt / tiles_k) * 32;
+#pragma unroll
+      for (int r = ty; r < 32; r += 8) {
+        const int co = c0 + r, k = k0 + tx;
+        tile[r][tx] = (co < it.Cout && k < K) ? it.src[(size_t)co * K + k] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, co = c0 + tx;
+        if (co < it.Cout) it.dst[(size_t)k * it.Cout + co] = tile[tx][r];
+      }
+      __syncthreads();
+    } else {
+      const int rows = (it.Cout * it.k + 31) / 32 * 32, tiles_r = rows / 32;
+      const int r0 = (lt % tiles_r) * 32, c0 = (lt / tiles_r) * 32;
+#pragma unroll
+      for (int r = ty; r < 32; r += 8) {
+        const int row = r0 + r, c = c0 + tx;
+        const int o = row / it.k, j = row - o * it.k;
+        if (c < it.Cin) it.dst[(size_t)row * it.Cin + c] = (o < it.Cout) ? it.src[((size_t)o * it.Cin + c) * it.k + (it.k - 1 - j)] : 0.f;
+      }
+    }
+  }
+}
 }  // namespace advhip
 
 using namespace advhip;
@@ -793,4 +836,16 @@ extern "C" int advhip_colsum_f32(const float* src, float* dst, int64_t rows, int
   ADVHIP_REQUIRE(src && dst && rows > 0 && cols > 0, "colsum: bad arguments");
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((cols + 31) / 32)), dim3(256), 0, (hipStream_t)stream, src, dst, (long long)rows, cols);
   return check_launch("colsum");
+}
+
+extern "C" int64_t advhip_pack_item_tiles(int32_t Cout, int32_t Cin, int32_t k, int32_t mode) {
+  if (Cout <= 0 || Cin <= 0 || k <= 0 || k > 10 || (mode != 0 && mode != 1)) return -1;
+  const int64_t K = (int64_t)Cin * k, rows = (int64_t)Cout * k;
+  return mode == 0 ? ((K + 31) / 32) * ((Cout + 31) / 32) : ((rows + 31) / 32) * ((Cin + 31) / 32);
+}
+
+extern "C" int advhip_pack_weights_multi_f32(const advhip_pack_item* items_dev, int32_t n_items, int32_t n_tiles, void* stream) {
+  ADVHIP_REQUIRE(items_dev && n_items > 0 && n_tiles > 0, "pack_weights_multi: bad arguments");
+  hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)std::min(n_tiles, 256 * 64)), dim3(256), 0, (hipStream_t)stream, items_dev, n_items, n_tiles);
+  return check_launch("pack_weights_multi");
 }

@@ -58,6 +58,9 @@ def eligible(cin: int, cout: int, x: torch.Tensor) -> bool:
 
 
 ALGO_SMALL = _lib.ALGO_DMA2_BASE + _lib.ALGO_IGEMM_64x64  # few output tiles: 64 x 64 tiles (+ split-K inside the launch)
+# >= 6 tiles of 128 x 128 per CU (the FFN's 1024 -> 4096 layers at 10 240 positions: 2 560): 144 TFLOP/s against the 128 x 64
+# tile's 124-141 there (tools/time_gemm_tiles.py); with fewer tiles (Cout = 1024: 640) the 128 x 64 tile's 145 wins over 122
+ALGO_WIDE = _lib.ALGO_DMA2_BASE + _lib.ALGO_IGEMM_128x128
 
 
 def _desc(cin: int, cout: int, k: int, b: int, t: int, act: int) -> ConvDesc:
@@ -65,7 +68,9 @@ def _desc(cin: int, cout: int, k: int, b: int, t: int, act: int) -> ConvDesc:
     n = b * t
     tiles128 = -(-n // 128) * (cout // 64)
     algo, splits = ALGO, 1
-    if tiles128 < 768:  # not enough 128 x 64 tiles for 256 CUs x 3: smaller tiles, and K slices when K is long
+    if cout % 128 == 0 and -(-n // 128) * (cout // 128) >= 1536:
+        algo = ALGO_WIDE
+    elif tiles128 < 768:  # not enough 128 x 64 tiles for 256 CUs x 3: smaller tiles, and K slices when K is long
         algo = ALGO_SMALL
         tiles = -(-n // 64) * (cout // 64)
         ktiles = -(-(cin * k) // 16)
@@ -115,6 +120,9 @@ def pack_kc_cached(param: torch.Tensor, fresh: bool = False) -> torch.Tensor:
     key = id(param)
     if fresh:
         _PACKED.pop(key, None)
+        live = _STEP_PACKS.get(key)  # (packed with every other weight of this forward in one launch: step_packs)
+        if live is not None and live[0]() is param:
+            return live[1]
         return pack_kc(param.detach())
     hit = _PACKED.get(key)
     stamp = (param.data_ptr(), param._version, tuple(param.shape), _EPOCH)
@@ -124,6 +132,62 @@ def pack_kc_cached(param: torch.Tensor, fresh: bool = False) -> torch.Tensor:
                 del _PACKED[k]
         hit = _PACKED[key] = (weakref.ref(param), stamp, pack_kc(param.detach()))
     return hit[2]
+
+
+# ---- the packed operands of one differentiated forward, all in one launch ------------------------------------------------------
+# id(param) -> (weakref, forward operand, input-gradient operand or None): valid between step_packs() and end_step_packs(),
+# i.e. inside ONE model forward.  The buffers are per-plan and static (a HIP graph can replay the launch); the next forward
+# overwrites them with the same values unless an optimizer step lies in between -- and a backward pass across an optimizer
+# step is not a thing autograd allows either.
+_STEP_PACKS: Dict[int, Tuple] = {}
+_PACK_PLANS: Dict[Tuple, Tuple] = {}
+
+
+def step_packs(convs) -> None:
+    """Pack, in ONE launch (advhip_pack_weights_multi_f32), the forward GEMM operand of every Conv1d in `convs` and the
+    transposed-conv operand of the k > 1 ones; until end_step_packs() the autograd Functions below take these instead of
+    packing layer by layer.  `convs`: nn.Conv1d modules (groups = 1) with contiguous fp32 weights on the current device."""
+    import numpy as np
+
+    ws = [c.weight for c in convs]
+    if not ws:
+        return
+    dev = ws[0].device
+    key = (dev,) + tuple((id(w), w.data_ptr(), tuple(w.shape)) for w in ws)
+    plan = _PACK_PLANS.get(key)
+    if plan is None:
+        lib = _lib.load()
+        item_t = np.dtype([("src", "<u8"), ("dst", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"), ("k", "<i4"), ("mode", "<i4"),
+                           ("tile_begin", "<i4"), ("reserved", "<i4")])
+        rows, bufs, tiles = [], {}, 0
+        for w in ws:
+            _lib.require_gpu(w)
+            cout, cin, k = w.shape
+            kc = torch.empty((-(-(cin * k) // 32) * 32, cout), device=dev, dtype=torch.float32)
+            dx = torch.empty((-(-(cout * k) // 32) * 32, cin), device=dev, dtype=torch.float32) if k > 1 else None
+            bufs[id(w)] = (weakref.ref(w), kc, dx)
+            for mode, dst in ((0, kc), (1, dx)):
+                if dst is None:
+                    continue
+                rows.append((w.data_ptr(), dst.data_ptr(), cout, cin, k, mode, tiles, 0))
+                tiles += int(lib.advhip_pack_item_tiles(cout, cin, k, mode))
+        items = torch.from_numpy(np.array(rows, dtype=item_t).view(np.uint8).copy()).to(dev)
+        if len(_PACK_PLANS) >= 4:  # (parameters of discarded models)
+            _PACK_PLANS.clear()
+        plan = _PACK_PLANS[key] = (items, len(rows), tiles, bufs)
+    items, n, tiles, bufs = plan
+    check(_lib.load().advhip_pack_weights_multi_f32(ptr(items), n, tiles, stream(ws[0])), "pack_weights_multi")
+    _STEP_PACKS.clear()
+    _STEP_PACKS.update(bufs)
+
+
+def end_step_packs() -> None:
+    _STEP_PACKS.clear()
+
+
+def _step_dx(weight: torch.Tensor) -> Optional[torch.Tensor]:
+    live = _STEP_PACKS.get(id(weight))
+    return live[2] if live is not None and live[0]() is weight else None
 
 
 def pack_kc(w: torch.Tensor) -> torch.Tensor:
@@ -304,6 +368,7 @@ class _LinearCN(torch.autograd.Function):
             y = conv_cn(x, pack_kc_cached(weight, fresh), cout, k, shift=shift, residual=res)
             ctx.save_for_backward(x, weight)
         ctx.unfolded = unfolded
+        ctx.dx_pack = _step_dx(weight) if k > 1 and fresh else None  # (packed with this forward's other operands: step_packs)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         # y = conv(x) + x (the blocks' `x = scc(x) + x`): dL/dx = conv^T(dy) + dy comes out of ONE launch (dy as the dX GEMM's
         # residual) instead of a GEMM, a pass-through and autograd's add over the whole activation
@@ -322,9 +387,11 @@ class _LinearCN(torch.autograd.Function):
                 dx = conv_cn(dy, weight.detach().view(cout, cin), cin, 1, residual=dy if fold else None)
             elif ctx.unfolded:  # transposed conv as a GEMM over unfold3(dY): rows (o*3 + j') = dY[o, n + j' - 1] against pack_dx's
                 ud = _unfold3(dy).view(3 * cout, dy.shape[1], dy.shape[2])  # [(o*3 + j')][c] = W[o][c][2 - j']
-                dx = conv_cn(ud, pack_dx(weight.detach()), cin, 1, residual=dy if fold else None)
+                wdx = ctx.dx_pack if ctx.dx_pack is not None else pack_dx(weight.detach())
+                dx = conv_cn(ud, wdx, cin, 1, residual=dy if fold else None)
             else:       # transposed conv: W'[c][o][j] = W[o][c][k-1-j], packed straight from the parameter (one launch)
-                dx = conv_cn(dy, pack_dx(weight.detach()), cin, k, residual=dy if fold else None)
+                wdx = ctx.dx_pack if ctx.dx_pack is not None else pack_dx(weight.detach())
+                dx = conv_cn(dy, wdx, cin, k, residual=dy if fold else None)
         with _Fork(dy, x) as fk:
             want_db = ctx.has_bias and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:  # dW = dY X^T, and db = rowsum(dY) out of the same launch

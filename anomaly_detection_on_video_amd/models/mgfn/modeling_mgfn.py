@@ -358,10 +358,28 @@ class MGFNModel(MGFNPreTrainedModel):
     def forward(self, x: torch.Tensor) -> MGFNModelOutput:
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             mgfn_ops.invalidate_caches()  # the weights are about to be updated: no cached packed copy may outlive this pass
-        # internal layout (C, B, T); `outputs` is returned in the reference's (B, C, T) shape (a view)
-        y = self.layers(self.amplifier(x))
+            if x.is_cuda and x.dtype == torch.float32 and x.device.index == torch.cuda.current_device():
+                mgfn_ops.step_packs(self._gemm_convs())  # ... and every GEMM layer's packed operand comes from one launch
+        try:
+            # internal layout (C, B, T); `outputs` is returned in the reference's (B, C, T) shape (a view)
+            y = self.layers(self.amplifier(x))
+        finally:
+            mgfn_ops.end_step_packs()
         mgfn_ops.flush_counters()  # (the BatchNorm layers' num_batches_tracked += 1, all in one launch)
         return MGFNModelOutput(outputs=y.permute(1, 0, 2))
+
+    def _gemm_convs(self):
+        """The Conv1d layers whose training forward runs on the HIP GEMMs (mgfn_ops.eligible's channel rules): their packed
+        operands are produced together."""
+        out = []
+        for m in self.modules():
+            if isinstance(m, nn.Conv1d) and m.groups == 1 and m.kernel_size[0] in (1, 3) and m.weight.requires_grad:
+                cout, cin, _k = m.weight.shape
+                w = m.weight
+                if (min(cin, cout) >= mgfn_ops.MIN_CHANNELS_TRAIN and cout % 64 == 0 and cin % 64 == 0 and w.is_cuda and w.dtype == torch.float32
+                        and w.is_contiguous() and w.device.index == torch.cuda.current_device()):
+                    out.append(m)
+        return out
 
 
 class MGFNForVideoAnomalyDetection(MGFNPreTrainedModel):

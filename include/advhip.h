@@ -363,6 +363,22 @@ int advhip_chan_layernorm_bwd_add_f32(const float* dy, const float* x, const flo
  * transpose + pack. */
 int advhip_conv1d_pack_weight_dx_f32(const float* w, float* w_packed, int32_t Cout, int32_t Cin, int32_t k, void* stream);
 
+/* Every packed operand a training step needs, in one launch: item i packs the Conv1d parameter `src` (Cout, Cin, k) into `dst`,
+ * mode 0 = advhip_conv3d_pack_weight_f32's [roundup32(Cin*k)][Cout] (the forward GEMM's operand), mode 1 =
+ * advhip_conv1d_pack_weight_dx_f32's [roundup32(Cout*k)][Cin] (the input gradient's).  `items_dev` is an array in DEVICE memory;
+ * tile_begin = the exclusive prefix sum of advhip_pack_item_tiles over the items, n_tiles their total.  Replaces the per-layer
+ * weight re-packs autograd's forward of nn.Conv1d hides inside MIOpen (modeling_mgfn.py:101-108,155,183-193). */
+typedef struct advhip_pack_item {
+  const float* src;
+  float* dst;
+  int32_t Cout, Cin, k;
+  int32_t mode;
+  int32_t tile_begin;
+  int32_t reserved;
+} advhip_pack_item;
+int64_t advhip_pack_item_tiles(int32_t Cout, int32_t Cin, int32_t k, int32_t mode);
+int advhip_pack_weights_multi_f32(const advhip_pack_item* items_dev, int32_t n_items, int32_t n_tiles, void* stream);
+
 /* dst[c] = sum over r, in row order, of src[r][c]: the per-block partial sums the backward kernels above leave to the caller
  * (rows = a few hundred blocks). */
 int advhip_colsum_f32(const float* src, float* dst, int64_t rows, int32_t cols, void* stream);

@@ -431,3 +431,37 @@ def test_head_layernorm_linear_sigmoid_fwd_bwd_vs_fp64_autograd(c, b, t):
     assert rel_err(yd.grad.cpu(), y64.grad) < 2e-5
     for got, want in ((ln.weight.grad, ln64.weight.grad), (ln.bias.grad, ln64.bias.grad), (fc.weight.grad, fc64.weight.grad), (fc.bias.grad, fc64.bias.grad)):
         assert rel_err(got.cpu(), want) < 2e-5
+
+
+def test_step_packs_equal_the_per_layer_packs_and_are_used_inside_one_forward():
+    """advhip_pack_weights_multi_f32: every forward / input-gradient operand of a step from one launch, bit for bit the
+    per-layer packs; offered to the autograd Functions only between step_packs() and end_step_packs()."""
+    from anomaly_detection_on_video_amd import mgfn_ops
+
+    convs = []
+    for i, (cout, cin, k) in enumerate([(128, 64, 1), (64, 128, 3), (1024, 256, 1), (192, 96, 3), (64, 64, 3), (64, 32, 1)]):
+        c = torch.nn.Conv1d(cin, cout, k, padding=k // 2).to(DEV)
+        with torch.no_grad():
+            c.weight.copy_(synth_tensor(f"step_pack_{i}", tuple(c.weight.shape)).to(DEV))
+        convs.append(c)
+    mgfn_ops.step_packs(convs)
+    try:
+        for c in convs:
+            got = mgfn_ops.pack_kc_cached(c.weight, fresh=True)
+            assert torch.equal(got, mgfn_ops.pack_kc(c.weight.detach()))
+            dx = mgfn_ops._step_dx(c.weight)
+            if c.kernel_size[0] > 1:
+                assert torch.equal(dx, mgfn_ops.pack_dx(c.weight.detach()))
+            else:
+                assert dx is None
+        first = mgfn_ops.pack_kc_cached(convs[0].weight, fresh=True)
+        # a second step over the same parameters replays into the same buffers (what a HIP graph of the step needs)
+        with torch.no_grad():
+            convs[0].weight.mul_(2.0)
+        mgfn_ops.step_packs(convs)
+        again = mgfn_ops.pack_kc_cached(convs[0].weight, fresh=True)
+        assert again.data_ptr() == first.data_ptr() and torch.equal(again, mgfn_ops.pack_kc(convs[0].weight.detach()))
+    finally:
+        mgfn_ops.end_step_packs()
+    fresh = mgfn_ops.pack_kc_cached(convs[0].weight, fresh=True)  # outside a forward: packed on the spot
+    assert fresh.data_ptr() != first.data_ptr() and mgfn_ops._step_dx(convs[1].weight) is None

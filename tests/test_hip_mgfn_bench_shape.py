@@ -106,8 +106,8 @@ def test_the_step_ran_on_the_benchmarked_kernels(step_records):
     assert n == 10240
     stage2 = [d for d in descs if min(d[0], d[1]) >= 1024 and d[3] > 1]  # (npos == 1: the descriptor of a weight re-pack)
     assert len(stage2) == 2 * (5 + 5), len(stage2)  # 2 blocks x (scc, to_v, to_out, in_conv, out_conv) x (forward, dX)
-    for cin, cout, k, npos, algo, splits in stage2:
-        assert npos == n and algo == mgfn_ops.ALGO and splits == 1, (cin, cout, k, npos, algo, splits)
+    for cin, cout, k, npos, algo, splits in stage2:  # (128 x 128 tiles for the 4096-wide outputs, 128 x 64 for the 1024-wide)
+        assert npos == n and algo == (mgfn_ops.ALGO_WIDE if cout == 4096 else mgfn_ops.ALGO) and splits == 1, (cin, cout, k, npos, algo, splits)
     # weight gradients dW = dY X^T: contraction over all 10 240 positions, stage-2 shapes present
     assert nts and all(kk == n for _a, _b, kk in nts), nts[:4]
     assert (4096, 1024, n) in nts and (1024, 4096, n) in nts and (1024, 3072, n) in nts

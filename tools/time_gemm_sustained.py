@@ -45,11 +45,12 @@ def main():
         Xs = [torch.randn(1, c, 1, 1, N, device=dev) for _ in range(8)]
         Ys = [torch.empty(1, o, 1, 1, N, device=dev) for _ in range(8)]
         hip = [lambda X=X, Y=Y: ops.conv3d_bn_act(X, pc, relu=False, algo=162, splits=1, out=Y) for X, Y in zip(Xs, Ys)]
+        hip128 = [lambda X=X, Y=Y: ops.conv3d_bn_act(X, pc, relu=False, algo=161, splits=1, out=Y) for X, Y in zip(Xs, Ys)]
         blas = [lambda X=X, Y=Y: torch.matmul(W.view(o, c), X.view(c, N), out=Y.view(o, N)) for X, Y in zip(Xs, Ys)]
         dY = [torch.randn(o, N, device=dev) for _ in range(8)]
         nt = [lambda A=A, X=X: ops.gemm_nt(A, X.view(c, N)) for A, X in zip(dY, Xs)]
         print(f"o={o} c={c} ({fl:.0f} GFLOP):", flush=True)
-        for name, fns in (("hip 128x64", hip), ("rocBLAS", blas), ("gemm_nt dW", nt)):
+        for name, fns in (("hip 128x64", hip), ("hip 128x128", hip128), ("rocBLAS", blas), ("gemm_nt dW", nt)):
             print(f"  {name:11s} burst/1set {rate(fns[:1], fl):6.1f}  burst/8sets {rate(fns, fl, reps=16):6.1f}  "
                   f"1.5s/1set {rate(fns[:1], fl, 1.5):6.1f}  1.5s/8sets {rate(fns, fl, 1.5):6.1f} TFLOP/s", flush=True)
 
