@@ -73,7 +73,7 @@ _L = C.c_int64
 
 
 class ConvEpilogue(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("y_preact", "dact_z", "ln_u", "ln_mu", "ln_rs")]
+    _fields_ = [(n, C.c_void_p) for n in ("y_preact", "dact_z", "ln_u", "ln_mu", "ln_rs", "splitk_counters")] + [("splitk_counter_bytes", C.c_int64)]
 
 
 class GemmDesc(C.Structure):
@@ -185,8 +185,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
             raise HipExtensionError(f"{p} does not export {name}; rebuild the extension") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.advhip_abi_version() != 1:
-        raise HipExtensionError(f"{p}: ABI version {lib.advhip_abi_version()} != 1; rebuild the extension")
+    if lib.advhip_abi_version() != 2:
+        raise HipExtensionError(f"{p}: ABI version {lib.advhip_abi_version()} != 2; rebuild the extension")
     if path is None:
         _lib = lib
     return lib

@@ -1336,6 +1336,9 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
     const bool last = *flag == (unsigned)(a.splits - 1);
     __syncthreads();  // the flag word is staging space again below
     if (!last) return;
+    // (the tile's counter goes back to zero for the next launch that uses it: a caller-owned counter block is zeroed once, when
+    // it is allocated -- advhip_conv3d_epilogue.splitk_counters -- and no memset runs ahead of the launch)
+    if (tid == 0) __hip_atomic_store(a.cnt + L, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // the last arriver: every slice of this tile has been published (write-through, drained before its ticket).  sc1
     // loads bypass this CU's L1 (never refreshed by other CUs' stores); sum in slice order -> run-to-run bit-identical
     // (in batches of G float4 per thread: the sums must not cost the main loop registers -- the occupancy target above
@@ -2533,8 +2536,15 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
   }
   dim3 grid((unsigned)(a.tiles_m * a.tiles_n * c.splits));
   hipStream_t st = (hipStream_t)stream;
-  if (a.cnt != nullptr) {  // arrival counters start every launch at zero (a memset node: graph-capturable, replayed first)
-    if (hipMemsetAsync(a.cnt, 0, (size_t)lay.cnt_bytes, st) != hipSuccess) return check_launch("conv3d split-K counters");
+  if (a.cnt != nullptr) {
+    const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
+    if (ep && ep->splitk_counters && ep->splitk_counter_bytes >= tiles * 4) {
+      // the caller's counter block: zero when allocated, and every launch leaves it zero (the last arriver of a tile resets its word)
+      ADVHIP_REQUIRE((uintptr_t)ep->splitk_counters % 4 == 0, "conv3d: misaligned split-K counter block");
+      a.cnt = reinterpret_cast<unsigned*>(ep->splitk_counters);
+    } else if (hipMemsetAsync(a.cnt, 0, (size_t)lay.cnt_bytes, st) != hipSuccess) {  // (a memset node: graph-capturable, replayed first)
+      return check_launch("conv3d split-K counters");
+    }
   }
   // BK = 32 needs Kpad % 32 == 0: the packed weights are padded to 16 rows only, but the k-table
   // marks rows >= K invalid and the weight rows read beyond Kpad must exist -> require it.

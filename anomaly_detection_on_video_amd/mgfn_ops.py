@@ -226,7 +226,9 @@ def conv_cn(x: torch.Tensor, w_packed: torch.Tensor, cout: int, k: int = 1, shif
     dev = x.device
     y = torch.empty((cout, b, t), device=dev, dtype=torch.float32)
     z = torch.empty_like(y) if want_preact else None
-    ep = ConvEpilogue(ptr(z), ptr(dact_z), ptr(ln[0]) if ln else None, ptr(ln[1]) if ln else None, ptr(ln[2]) if ln else None)
+    cnt = ops.splitk_counters(dev) if d.splits > 1 else None  # (self-resetting arrival counters: no memset ahead of the launch)
+    ep = ConvEpilogue(ptr(z), ptr(dact_z), ptr(ln[0]) if ln else None, ptr(ln[1]) if ln else None, ptr(ln[2]) if ln else None,
+                      ptr(cnt), cnt.numel() * 4 if cnt is not None else 0)
     for tns in (residual, dact_z):
         if tns is not None and (tuple(tns.shape) != (cout, b, t) or not tns.is_contiguous()):
             raise ValueError("conv_cn: residual / dact_z must be contiguous (Cout, B, T)")

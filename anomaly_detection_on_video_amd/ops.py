@@ -172,6 +172,19 @@ def zeroed_workspace(dev: torch.device, nbytes: int) -> Optional[torch.Tensor]:
     return ws
 
 
+_SPLITK_COUNTERS: Dict[Tuple[torch.device, int], torch.Tensor] = {}
+
+
+def splitk_counters(dev: torch.device) -> torch.Tensor:
+    """The arrival-counter block of the in-launch split-K reduction for launches on the current stream of `dev`
+    (include/advhip.h: advhip_conv3d_epilogue.splitk_counters): zero-filled ONCE here; every launch leaves it zero."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    cnt = _SPLITK_COUNTERS.get(key)
+    if cnt is None:
+        cnt = _SPLITK_COUNTERS[key] = torch.zeros((16384,), device=dev, dtype=torch.int32)
+    return cnt
+
+
 def batch_stride(t: torch.Tensor) -> int:
     """Elements between consecutive samples of an NCDHW tensor that is contiguous per sample: a contiguous tensor,
     or a channel slice `wide[:, a:b]` of one (the kernels take the batch stride; everything inside a sample must be
@@ -213,13 +226,13 @@ def conv3d_bn_act(x: torch.Tensor, pc: PackedConv, relu: bool = True, residual: 
     w = pc.w_packed
     if _lib.ALGO_BF16X3_BASE <= d.algo < _lib.ALGO_DMA2_BASE:
         w = split_weight(pc)
-    xbs, ybs = batch_stride(x), batch_stride(y)
-    if xbs == pc.cin * T * H * W and ybs == pc.cout * to * ho * wo:
-        check(lib.advhip_conv3d_bn_act_f32(C.byref(d), ptr(x), ptr(w), ptr(ktab), ptr(pc.scale), ptr(pc.shift),
-                                           ptr(residual), ptr(y), ptr(ws), need, stream()), f"conv3d[{pc.name}]")
-    else:  # x and / or y is a channel slice of a wider tensor
-        check(lib.advhip_conv3d_bn_act_strided_f32(C.byref(d), ptr(x), xbs, ptr(w), ptr(ktab), ptr(pc.scale), ptr(pc.shift),
-                                                   ptr(residual), ptr(y), ybs, ptr(ws), need, stream()), f"conv3d[{pc.name}]")
+    xbs, ybs = batch_stride(x), batch_stride(y)  # (x and / or y may be a channel slice of a wider tensor)
+    ep = None
+    if need > 0:  # split-K: this stream's self-resetting arrival counters instead of a memset ahead of every launch
+        cnt = splitk_counters(x.device)
+        ep = C.byref(_lib.ConvEpilogue(None, None, None, None, None, ptr(cnt), cnt.numel() * 4))
+    check(lib.advhip_conv3d_bn_act_ex_f32(C.byref(d), ptr(x), xbs, ptr(w), ptr(ktab), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(y), ybs,
+                                          ep, ptr(ws), need, stream()), f"conv3d[{pc.name}]")
     return y
 
 

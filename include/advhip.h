@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ADVHIP_ABI_VERSION 1
+#define ADVHIP_ABI_VERSION 2
 
 #define ADVHIP_OK 0
 #define ADVHIP_EINVAL (-1)   /* bad shape / null pointer / unsupported configuration */
@@ -138,13 +138,21 @@ int advhip_conv3d_bn_act_strided_f32(const advhip_conv3d_desc* d, const float* x
  *   ln_u / ln_mu / ln_rs (nullable, together): the channel-LayerNorm fold for a 1x1x1 conv -- with w_packed holding
  *            W.diag(g) and ln_u[n] its row sums, v = acc * ln_rs[m] - ln_u[n] * ln_mu[m] * ln_rs[m] turns the conv of the RAW
  *            activation into W.LN(x) minus the W.b term (put W.b + bias in `shift`): MGFNLayerNorm (:36-46) never
- *            materialises; ln_mu / ln_rs are per position m (advhip_chan_stats_f32). */
+ *            materialises; ln_mu / ln_rs are per position m (advhip_chan_stats_f32).
+ * A zero-filled struct = advhip_conv3d_bn_act_strided_f32. */
 typedef struct advhip_conv3d_epilogue {
   float* y_preact;
   const float* dact_z;
   const float* ln_u;
   const float* ln_mu;
   const float* ln_rs;
+  /* ABI 2.  Nullable: a caller-owned block of arrival counters for the in-launch split-K reduction, 4 bytes per output tile
+   * (65 536 bytes cover every shape of the I3D / MGFN plans).  Contract: ZERO when first handed over, used by one stream at a
+   * time, never written by the caller afterwards -- each launch leaves it zero (the last arriver of a tile resets its word), so
+   * no memset node runs ahead of the launch.  Without it (or if it is too small) the counters live at the head of
+   * `workspace` and are cleared by a memset before every launch. */
+  void* splitk_counters;
+  int64_t splitk_counter_bytes;
 } advhip_conv3d_epilogue;
 int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const float* x, int64_t x_batch_stride, const float* w_packed,
                                 const int32_t* ktab, const float* scale, const float* shift, const float* residual, float* y,

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/advhip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == declared
-    assert lib.advhip_abi_version() == 1
+    assert lib.advhip_abi_version() == 2
     assert lib.advhip_target_arch() == b"gfx950"
 
 
