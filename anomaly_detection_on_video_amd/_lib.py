@@ -73,7 +73,8 @@ _L = C.c_int64
 
 
 class ConvEpilogue(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("y_preact", "dact_z", "ln_u", "ln_mu", "ln_rs", "splitk_counters")] + [("splitk_counter_bytes", C.c_int64)]
+    _fields_ = ([(n, C.c_void_p) for n in ("y_preact", "dact_z", "ln_u", "ln_mu", "ln_rs", "splitk_counters")] + [("splitk_counter_bytes", C.c_int64)]
+                + [("avgpool_out", C.c_void_p)])
 
 
 class GemmDesc(C.Structure):

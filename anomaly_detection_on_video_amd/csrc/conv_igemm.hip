@@ -97,6 +97,7 @@ struct ConvArgs {
   // AMODE 1 (stride-2-along-w stem on column-parity planes, see split_w_kernel): x = xs (B, Cin, T, H, 2, WP)
   const int2* ktab_s2w;  // [Kpad] {byte offset of the tap's 4-column piece relative to the group's window origin, (dt, dh) tap bits}
   int s2w_rowp;          // floats per input row of xs (both parities): 2 * WP
+  float* avg_out;     // EPI_AVG: (B, Cout) means over the sample's positions (the conv's own output is never written)
   float* y2;          // nullable: the pre-activation value (after scale/shift/residual), y's addressing -- saved for backward
   const float* dact;  // nullable: z of a GELU, y's addressing (dense): the result is multiplied by gelu'(z) (fused GELU backward)
   // nullable LayerNorm fold (1x1x1 convs over a (C, positions) activation): conv(W.diag(g), x_raw) -> W.LN(x) - W.b:
@@ -634,7 +635,10 @@ enum : int {
   EPI_TSPAN2 = 4,   // plain output, m-tiles that span T: brick 2(t) x BM/2 flattened (h,w) of a (kt,1,1) conv -- the kt temporal taps
   EPI_TSPAN4 = 5,   //   of a tile read the SAME activation rows (shifted by one plane), so they hit L1/L2 instead of being fetched by
                     //   three m-tiles that run ~47 tiles apart; 4(t) x BM/4 for T = 4
+  EPI_AVG = 6,      // + AdaptiveAvgPool3d((1,1,1)) (src/i3d.py:314): a 1x1x1 conv on <= 128 positions per sample, every sample's rows
+                    //   padded to ONE 128-row m-tile in the m index space (ConvArgs::MP = 128): the tile's column means are the result
 };
+constexpr bool epi_rows(int epi) { return epi == EPI_STD || epi == EPI_AVG; }  // m runs (sample, position) row-major (no bricks)
 constexpr int brick_t(int epi) { return epi == EPI_TSPAN4 ? 4 : 2; }
 
 // ---- pooling epilogues on brick-ordered tiles (128 x 64 tile, 2 x 2 waves) ----------------------------------------------
@@ -942,6 +946,56 @@ constexpr int dma_waves_per_simd() {
 // and one wave-instruction fills two whole k-rows of the [k][128 m] tile -- 2 A instructions per wave and k-tile instead of
 // 8.  The stem is bound by the issue slots its LDS-DMA instructions share with the MFMAs (82 % MFMA-busy); same K order,
 // same operands, same accumulation: bit-identical to the 4-byte gather.
+// ---- EPI_AVG: the mean over a sample's positions instead of the output tensor ----------------------------------------------------
+// Tile = one sample (rows >= THWo are padding and count as zero) x 64 channels.  Per fragment column the waves transpose through
+// LDS as igemm_epilogue's unaligned path does (lane = position: coalesced residual reads), apply scale / shift / residual /
+// activation, and add the 64 positions of their chunk with the butterfly below; chunk 0 + chunk 1, divided by THWo, is the mean.
+// advhip_global_avgpool_f32 adds in the SAME order (pool.hip), so the fused launch equals conv + pool bit for bit.
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <int BM, int BN, int BK>
+__device__ __forceinline__ void avg_epilogue(const ConvArgs& a, f32x4 (&acc)[BM / 32][BN / 32], float* smem, int b, int n0, int wave, int lane, int tid) {
+  using Cfg = IgemmCfg<BM, BN, BK>;
+  static_assert(BM == 128 && BN == 64, "one sample per 128-row tile, 2 x 2 waves");
+  constexpr int FN = Cfg::FN;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lg = lane >> 4;
+  float* st = smem + wave * (16 * Cfg::ST_STRIDE);
+  float* part = smem + Cfg::ST_FLOATS;  // [2 chunks of 64 positions][64 channels]
+  const int pp = wm * 64 + lane;        // this lane's position in the read phase
+  const bool mok = pp < a.THWo;
+#pragma unroll
+  for (int jn = 0; jn < FN; ++jn) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<float4*>(&st[li * Cfg::ST_STRIDE + 16 * lg + 4 * r]) = make_float4(acc[0][jn][r], acc[1][jn][r], acc[2][jn][r], acc[3][jn][r]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int row = 0; row < 16; ++row) {
+      const int c = wn * Cfg::WN + FN * row + jn, n = n0 + c;
+      float v = 0.f;
+      if (mok) {
+        v = st[row * Cfg::ST_STRIDE + lane] * a.scale[n] + a.shift[n];
+        if (a.res) v += a.res[((size_t)b * a.Cout + n) * a.THWo + pp];
+        if (a.relu) v = act_apply(a.relu, v);
+      }
+      v = wave_sum64(v);
+      if (lane == 0) part[wm * 64 + c] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  __syncthreads();
+  if (tid < 64) a.avg_out[(size_t)b * a.Cout + n0 + tid] = (part[tid] + part[64 + tid]) / (float)a.THWo;
+}
+
 template <int BM, int BN, int BK, bool CHECK, int NS = 3, int EPI = EPI_STD, bool U8 = false, int AMODE = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dma_waves_per_simd<BM, BN, BK, NS>(), 8)))
 void conv3d_igemm_dma_kernel(const ConvArgs a) {
@@ -952,10 +1006,11 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   static_assert(LB >= 1 && LA >= 1 && (NS - 2) * (LA + LB) <= 63, "tile / vmcnt budget");
   constexpr unsigned OOB = 0xFFFFFF00u;
   constexpr int RING = NS * D::STAGE;
-  constexpr int BRICK_FLOATS = EPI == EPI_STD ? 0 : (BN / Cfg::FN) * (BM + 4);  // one fragment column of every wave: [BN/FN channels][BM + 4]
+  constexpr int BRICK_FLOATS = EPI == EPI_STD ? 0 : (EPI == EPI_AVG ? Cfg::ST_FLOATS + 2 * BN : (BN / Cfg::FN) * (BM + 4));  // one fragment column of every wave: [BN/FN channels][BM + 4]
   constexpr int SMEM0 = RING > Cfg::ST_FLOATS ? RING : Cfg::ST_FLOATS;
   constexpr int SMEM = SMEM0 > BRICK_FLOATS ? SMEM0 : BRICK_FLOATS;
   static_assert(EPI == EPI_STD || (BM == 128 && BN == 64), "pooling epilogues: 128 x 64 tile (wave row = one t plane of the brick)");
+  static_assert(EPI != EPI_AVG || (!CHECK && NS == 2 && !U8 && AMODE == 0), "the mean epilogue: 1x1x1 convs on the 2-deep ring");
   static_assert(!U8 || (EPI == EPI_POOL233 && CHECK), "uint8 frame input: the stem + maxpool1 form (an m-tile lies in one crop)");
   constexpr int BRICK_T = brick_t(EPI), BRICK_H = EPI == EPI_POOL233 ? 4 : 1, BRICK_W = BM / (BRICK_T * BRICK_H);
 
@@ -990,7 +1045,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   int pb = 0, pot = 0, poh = 0, pow_ = 0;
   bool pvalid;
   int bk_b = 0, bk_t = 0, bk_h = 0, bk_w = 0;  // brick forms: sample and brick coordinates of this m-tile
-  if constexpr (EPI == EPI_STD) {
+  if constexpr (epi_rows(EPI)) {
     pvalid = m < a.M;
     if (pvalid) {
       pb = (int)a.dTHWo.div((unsigned)m);
@@ -1101,7 +1156,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   // wave: 4x fewer VMEM issues per tile (the LDS-DMA issue of the 4-byte form costs ~10 % of such a kernel,
   // profiles/r01_pmc_notes.md).  Tap offsets are linear in k here (k * THW), so no table is read.  2-deep ring only: its
   // waits are vmcnt(0) whatever the number of pieces.
-  constexpr bool CAN16 = !CHECK && NS == 2 && EPI == EPI_STD;
+  constexpr bool CAN16 = !CHECK && NS == 2 && epi_rows(EPI);
   constexpr int RPI16 = 256 / BM, LA16 = BK * BM / 1024;
   static_assert(LA16 >= 1, "tile too small for 16-byte A pieces");
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1363,7 +1418,10 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
       }
     }
   }
-  if constexpr (EPI != EPI_STD) {
+  if constexpr (EPI == EPI_AVG) {
+    avg_epilogue<BM, BN, BK>(a, acc, smem, tile_m, n0, wave, lane, tid);
+    return;
+  } else if constexpr (EPI != EPI_STD) {
     brick_epilogue<BM, BN, BK, EPI, U8>(a, acc, smem, tile_m, tile_n, n0, bk_b, bk_t, bk_h, bk_w, wave, lane, tid, u8c);
     return;
   }
@@ -2407,10 +2465,11 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
   if (int rc = validate(d)) return rc;
   float* y_preact = ep ? ep->y_preact : nullptr;
   const float* dact_z = ep ? ep->dact_z : nullptr;
+  float* avg_out = ep ? ep->avgpool_out : nullptr;
   const bool ln = ep && ep->ln_u;
   ADVHIP_REQUIRE(!ep || (!ep->ln_u == !ep->ln_mu && !ep->ln_u == !ep->ln_rs), "conv3d: the LayerNorm fold needs ln_u, ln_mu and ln_rs together");
   ADVHIP_REQUIRE(d->relu >= 0 && d->relu <= 2, "conv3d: unknown activation code %d (0 none, 1 ReLU, 2 GELU)", d->relu);
-  ADVHIP_REQUIRE(x && w_packed && ktab && scale && shift && y, "conv3d: null pointer");
+  ADVHIP_REQUIRE(x && w_packed && ktab && scale && shift && (y || avg_out), "conv3d: null pointer");
   const Geometry g = geometry(d);
   ConvArgs a;
   a.x = x; a.w = w_packed; a.ktab = reinterpret_cast<const int4*>(ktab);
@@ -2451,6 +2510,14 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
   a.vw = aligned_to(4) ? 4 : (aligned_to(2) ? 2 : 1);
 
   Choice c = choose(d, M, g.Kpad);
+  if (avg_out != nullptr) {  // conv + global mean in one launch: one sample per 128-row tile of the 2-deep LDS-DMA kernel, unsplit
+    ADVHIP_REQUIRE(d->kt == 1 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->ph == 0 && d->pw == 0 &&
+                       g.K == g.Kpad && a.THWo <= 128 && d->Cout % 64 == 0 && ((uintptr_t)x & 15) == 0 && !ln && y_preact == nullptr && dact_z == nullptr,
+                   "conv3d: avgpool_out needs a 1x1x1 stride-1 conv on <= 128 positions per sample (%d), Cin %% 16 == 0, Cout %% 64 == 0, x 16-byte aligned, "
+                   "no other epilogue operand", a.THWo);
+    c.algo = ADVHIP_ALGO_DMA2_BASE + ADVHIP_ALGO_IGEMM_128x64;
+    c.splits = 1;
+  }
   if (ybs != y_dense && !reduces_in_kernel(c.algo)) c.splits = 1;  // the separate split-K reduce pass writes a dense y
   ADVHIP_REQUIRE(!ln || (d->kt == 1 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->ph == 0 && d->pw == 0),
                  "conv3d: the LayerNorm fold applies to 1x1x1 stride-1 convs (per-position statistics of the input)");
@@ -2510,6 +2577,15 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
       a.MP = a.THWo;
       Mv = M;
     }
+  }
+  if (avg_out != nullptr) {  // (the same virtual padding, to the whole tile: the last groups of a sample read on into rows nobody adds up)
+    a.MP = 128;
+    Mv = (long long)d->B * a.MP;
+    ADVHIP_REQUIRE(Mv < (1ll << 31), "conv3d: too many samples for the fused mean");
+    a16pad = true;
+    a.M = (int)Mv;
+    a.dTHWo = FastDiv::make((unsigned)a.MP);
+    a.avg_out = avg_out;
   }
   a.tiles_m = (int)((Mv + BM - 1) / BM);
   a.tiles_n = d->Cout / BN;
@@ -2580,6 +2656,10 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
     if (nocheck) hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BN_, false>), grid, dim3(256), 0, st, a);          \
     else hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BN_, true>), grid, dim3(256), 0, st, a);                   \
     break;
+  if (avg_out != nullptr) {
+    hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, false, 2, EPI_AVG>), grid, dim3(256), 0, st, a);
+    return check_launch("conv3d + mean");
+  }
   switch (c.algo) {
     case ADVHIP_ALGO_TSPAN_128x64:
       if (tspan_bt == 4) hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, true, 2, EPI_TSPAN4, false, 1>), grid, dim3(256), 0, st, a);

@@ -103,12 +103,24 @@ __global__ void maxpool3d_t_kernel(const float* __restrict__ x, float* __restric
   }
 }
 
-// One wavefront per row: lanes stride the row, then a 64-wide shuffle reduction.
+// One wavefront per row.  Rows of <= 128 positions (the I3D head: 2 x 7 x 7 = 98) are added exactly as the conv kernel's fused
+// mean epilogue adds them (conv_igemm.hip, EPI_AVG): positions 0..63 and 64..127 each with the xor butterfly, chunk 0 + chunk 1,
+// divided by n -- conv + this launch and the fused launch agree bit for bit.  Longer rows: lanes stride the row first.
 __global__ void global_avgpool_kernel(const float* __restrict__ x, float* __restrict__ y, long long rows, int n) {
   const int lane = threadIdx.x & 63;
   const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* p = x + row * n;
+  if (n <= 128) {
+    float s0 = lane < n ? p[lane] : 0.f, s1 = 64 + lane < n ? p[64 + lane] : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      s0 += __shfl_xor(s0, off, 64);
+      s1 += __shfl_xor(s1, off, 64);
+    }
+    if (lane == 0) y[row] = (s0 + s1) / (float)n;
+    return;
+  }
   float s = 0.f;
   for (int i = lane; i < n; i += 64) s += p[i];
 #pragma unroll

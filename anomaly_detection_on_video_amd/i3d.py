@@ -256,6 +256,9 @@ class I3Res50(nn.Module):
             elif (prev.kind == "bottleneck" and not prev.cat and (u.kernel, u.stride) == ((2, 1, 1), (2, 1, 1))
                   and prev.convs[2].kernel == (1, 1, 1) and prev.convs[2].stride == (1, 1, 1) and prev.convs[2].cin % 32 == 0):
                 prev.pool_unit, u.absorbed = u, True
+        # ... and the global mean behind the last bottleneck into its conv3 (src/i3d.py:314): skipped the same way
+        if len(plan) >= 2 and plan[-1].kind == "avgpool" and plan[-2].kind == "bottleneck" and not plan[-2].cat and plan[-2].pool_unit is None:
+            plan[-2].pool_unit, plan[-1].absorbed = plan[-1], True
         self._plan, self._plan_stamp = plan, stamp
 
     def packed_convs(self) -> List[ops.PackedConv]:
@@ -484,6 +487,10 @@ class _Unit:
         h = ops.conv3d_bn_act(x, c1, relu=True)
         h = ops.conv3d_bn_act(h, c2, relu=True)
         res = ops.conv3d_bn_act(x, ds, relu=False) if ds is not None else x
+        if fused and self.pool_unit.kind == "avgpool":  # conv3 + bn3 + residual + relu + avgpool (src/i3d.py:111-121, 314) in one launch
+            if ops.FUSE_AVGPOOL and ops.avgpool_fusable(c3, tuple(h.shape[2:])):
+                return ops.conv3d_bn_act_avgpool(h, c3, relu=True, residual=res)
+            return ops.global_avgpool(ops.conv3d_bn_act(h, c3, relu=True, residual=res))  # (the pool unit itself is skipped)
         if fused:  # conv3 + bn3 + residual + relu + maxpool2 (src/i3d.py:111-121, 309) in one launch
             return ops.conv3d_bn_act_maxpool211(h, c3, relu=True, residual=res)
         return ops.conv3d_bn_act(h, c3, relu=True, residual=res)

@@ -519,6 +519,32 @@ def maxpool3d(x: torch.Tensor, kernel, stride, out: Optional[torch.Tensor] = Non
     return y
 
 
+FUSE_AVGPOOL = os.environ.get("ADV_I3D_FUSE_AVGPOOL", "1") == "1"
+
+
+def avgpool_fusable(pc: PackedConv, thw: Tuple[int, int, int]) -> bool:
+    """conv3d_bn_act_avgpool takes this conv on (T,H,W) inputs (include/advhip.h: advhip_conv3d_epilogue.avgpool_out)."""
+    return (pc.kernel == (1, 1, 1) and pc.stride == (1, 1, 1) and pc.padding == (0, 0, 0) and thw[0] * thw[1] * thw[2] <= 128
+            and pc.cout % 64 == 0 and pc.cin % 32 == 0)
+
+
+def conv3d_bn_act_avgpool(x: torch.Tensor, pc: PackedConv, relu: bool = True, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """global_avgpool(act(conv3d(x) * scale + shift (+ residual))) -> (B, Cout, 1, 1, 1) in ONE launch: the conv's own output is
+    never written.  Bit for bit global_avgpool(conv3d_bn_act(...)) (src/i3d.py:111-121 + 314)."""
+    require_gpu(x, residual)
+    B, _, T, H, W = x.shape
+    if x.shape[1] != pc.cin or not avgpool_fusable(pc, (T, H, W)):
+        raise ValueError(f"{pc.name}: conv + mean in one launch needs a 1x1x1 stride-1 conv on <= 128 positions, got {tuple(x.shape)}")
+    if residual is not None and tuple(residual.shape) != (B, pc.cout, T, H, W):
+        raise ValueError(f"{pc.name}: residual {tuple(residual.shape)} != output {(B, pc.cout, T, H, W)}")
+    y = torch.empty((B, pc.cout, 1, 1, 1), device=x.device, dtype=torch.float32)
+    d = pc.desc(B, T, H, W, relu, _lib.ALGO_DMA2_BASE + _lib.ALGO_IGEMM_128x64, 1)
+    ep = _lib.ConvEpilogue(None, None, None, None, None, None, 0, ptr(y))
+    check(_lib.load().advhip_conv3d_bn_act_ex_f32(C.byref(d), ptr(x), 0, ptr(pc.w_packed), ptr(ensure_ktab(pc, (T, H, W))), ptr(pc.scale),
+                                                  ptr(pc.shift), ptr(residual), None, 0, C.byref(ep), None, 0, stream()), f"conv3d+mean[{pc.name}]")
+    return y
+
+
 def global_avgpool(x: torch.Tensor) -> torch.Tensor:
     """(B,C,T,H,W) -> (B,C,1,1,1)"""
     require_gpu(x)

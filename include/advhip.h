@@ -153,6 +153,12 @@ typedef struct advhip_conv3d_epilogue {
    * `workspace` and are cleared by a memset before every launch. */
   void* splitk_counters;
   int64_t splitk_counter_bytes;
+  /* ABI 2.  Nullable: (B, Cout) -- the launch writes the mean of act(conv * scale + shift (+ residual)) over each sample's
+   * positions here INSTEAD of y (which may then be null): layer4's last conv3 + bn3 + residual + ReLU and the
+   * nn.AdaptiveAvgPool3d((1,1,1)) behind it (src/i3d.py:111-121, 314) in one launch.  1x1x1 stride-1 convs on <= 128
+   * positions per sample, Cout % 64 == 0, x 16-byte aligned, none of the operands above; bit for bit
+   * advhip_global_avgpool_f32 of the conv's own output. */
+  float* avgpool_out;
 } advhip_conv3d_epilogue;
 int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const float* x, int64_t x_batch_stride, const float* w_packed,
                                 const int32_t* ktab, const float* scale, const float* shift, const float* residual, float* y,

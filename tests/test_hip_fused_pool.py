@@ -158,17 +158,53 @@ def test_fullnet_fused_pools_equal_unfused_plan():
     m = I3Res50(use_nl=False)
     m.load_state_dict(synth_i3d_state_dict(), strict=True)
     m = m.eval().to(_dev())
-    assert m.fuse_pool
+    from anomaly_detection_on_video_amd import ops
+
+    assert m.fuse_pool and ops.FUSE_AVGPOOL
     for shape, seed in (((2, 3, 16, 224, 224), 0), ((3, 3, 8, 112, 96), 7), ((16, 3, 16, 64, 80), 2)):
         x = synth_input(shape, seed).to(_dev())
-        m.fuse_pool = True
-        y_f = m(x)
-        m.fuse_pool = False
-        y_u = m(x)
-        m.fuse_pool = True
+        try:
+            ops.FUSE_AVGPOOL = False  # the max-pool fusions alone: every other launch is the same one
+            m.fuse_pool = True
+            y_f = m(x)
+            m.fuse_pool = False
+            y_u = m(x)
+            m.fuse_pool = True
+        finally:
+            ops.FUSE_AVGPOOL = True
         # small inputs: the un-fused convs may run split-K (another fp32 summation order); otherwise the same bits
         assert torch.equal(y_f, y_u) if shape[-1] == 224 else rel_err(y_f.cpu(), y_u.cpu()) < 1e-5, f"{shape}: max diff {float((y_f - y_u).abs().max()):.3e}"
-    assert sum(1 for u in m._plan if u.absorbed) == 2
+        # ... and with the global mean folded into layer4.2.conv3 (always unsplit on its 128 x 64 tile; the conv it replaces
+        # may run split-K at small batches: same values up to the fp32 summation order)
+        y_a = m(x)
+        assert rel_err(y_a.cpu(), y_f.cpu()) < 1e-6, f"{shape}: max diff {float((y_a - y_f).abs().max()):.3e}"
+    assert sum(1 for u in m._plan if u.absorbed) == 3
     taps = {}
     m.forward_single(synth_input((1, 3, 16, 224, 224), 1).to(_dev()), taps)
     assert tuple(taps["stem"].shape) == (1, 64, 8, 112, 112) and tuple(taps["layer1.2"].shape) == (1, 256, 4, 55, 55)
+
+
+AVG_CASES = [(32, 512, 2048, (2, 7, 7), True), (5, 512, 2048, (2, 7, 7), False), (3, 64, 128, (2, 8, 8), True), (2, 96, 64, (1, 8, 8), True),
+             (4, 32, 64, (1, 2, 2), True), (1, 256, 192, (3, 5, 7), False)]
+
+
+@pytest.mark.parametrize("case", AVG_CASES, ids=[str(c) for c in AVG_CASES])
+def test_conv_avgpool_in_one_launch_is_bit_exact(case):
+    """conv3 + bn3 + residual + ReLU + AdaptiveAvgPool3d((1,1,1)) (/root/reference/src/i3d.py:111-121, 314) in one launch
+    (advhip_conv3d_epilogue.avgpool_out) vs the conv launch (unsplit) followed by advhip_global_avgpool_f32: the same bits; 98,
+    128, 64, 4 and 105 positions per sample; and within 1e-5 of torch's mean."""
+    from anomaly_detection_on_video_amd import _lib, ops
+
+    b, cin, cout, thw, with_res = case
+    pc, _ = _pack(f"avg{cin}x{cout}", cin, cout, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    x = synth_tensor(f"fp.avg.x.{case}", (b, cin) + thw, scale=2.0).to(_dev())
+    res = synth_tensor(f"fp.avg.r.{case}", (b, cout) + thw, scale=1.0).to(_dev()) if with_res else None
+    assert ops.avgpool_fusable(pc, thw)
+    got = ops.conv3d_bn_act_avgpool(x, pc, relu=True, residual=res)
+    full = ops.conv3d_bn_act(x, pc, relu=True, residual=res, algo=_lib.ALGO_DMA2_BASE + _lib.ALGO_IGEMM_64x64, splits=1)
+    want = ops.global_avgpool(full)
+    assert tuple(got.shape) == (b, cout, 1, 1, 1)
+    assert torch.equal(got, want), f"max diff {float((got - want).abs().max()):.3e}"
+    assert rel_err(got.cpu(), full.mean(dim=(2, 3, 4), keepdim=True).cpu()) < 1e-5
+    with pytest.raises(ValueError):
+        ops.conv3d_bn_act_avgpool(torch.zeros((1, cin, 3, 7, 7), device=_dev()), pc)  # 147 positions: more than one tile

@@ -63,9 +63,9 @@ def _assert_tuned_plan(model, batch: int, table=None):
     seen = 0
     fused_pool = {u.convs[0].name for u in model._plan if u.kind == "stem" and u.pool_unit is not None}
     fused_pool |= {u.convs[2].name for u in model._plan if u.kind == "bottleneck" and u.pool_unit is not None}
-    assert fused_pool == ({"conv1", "layer1.2.conv3"} if model.fuse_pool else set())
+    assert fused_pool == ({"conv1", "layer1.2.conv3", "layer4.2.conv3"} if model.fuse_pool else set())
     for pc in model.packed_convs():
-        if pc.name in fused_pool:  # conv + max-pool launches have one tile configuration (128x64x16 bricks), no table entry
+        if pc.name in fused_pool:  # conv + pool launches have one tile configuration (128x64x16; bricks / one sample per tile), no table entry
             continue
         keys = [k for k in pc.choices if k[0] == batch]
         assert keys, f"{pc.name}: no choice resolved for batch {batch}"
@@ -74,7 +74,7 @@ def _assert_tuned_plan(model, batch: int, table=None):
             assert entry is not None, f"{pc.name}: {pc.key(*k)} missing from the tuned table (heuristic would run)"
             assert tuple(pc.choices[k]) == tuple(entry), f"{pc.name}: ran {pc.choices[k]}, table says {entry}"
             seen += 1
-    assert seen >= 50  # 53 convs, layer1.0's downsample folded into conv3, two convs fused with their max-pool
+    assert seen >= 49  # 53 convs, layer1.0's downsample folded into conv3, two convs fused with their max-pool, one with the mean
 
 
 @pytest.mark.parametrize("batch,streams", [(32, 1), (32, 2), (8, 1), (16, 1), (40, 1)])
