@@ -19,6 +19,11 @@ def load(pattern):
     return list(csv.DictReader(open(f[0]))) if f else []
 
 
+def forward_end(name):
+    """The last launch of a forward (or of one stream part): global_avgpool, or the conv whose epilogue takes the mean (EPI_AVG = 6)."""
+    return "global_avgpool" in name or "conv3d_igemm_dma_kernel<128, 64, 16, false, 2, 6," in name
+
+
 def family(name):
     if "conv3d_igemm" in name or "splitk_reduce" in name:
         return "conv"
@@ -37,7 +42,7 @@ def main():
     ap.add_argument("--write", default="")
     ap.add_argument("--mfma", default="", help="PMC pass with SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA")
     ap.add_argument("--out", required=True)
-    ap.add_argument("--parts", type=int, default=2, help="stream parts a forward is split into (global_avgpool launches per forward)")
+    ap.add_argument("--parts", type=int, default=2, help="stream parts a forward is split into (global_avgpool / fused-mean launches per forward)")
     a = ap.parse_args()
     rows = load(os.path.join(a.trace, "*_kernel_trace.csv"))
     # dispatch ids follow launch order, and a forward's launches are issued back to back by one host thread, so a
@@ -45,7 +50,7 @@ def main():
     # consecutive steps run on different HIP streams and overlap in time
     rows.sort(key=lambda r: int(r.get("Dispatch_Id") or r["Start_Timestamp"]))
     dur = lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    ends = [i for i, r in enumerate(rows) if "global_avgpool" in r["Kernel_Name"]][a.parts - 1 :: a.parts]
+    ends = [i for i, r in enumerate(rows) if forward_end(r["Kernel_Name"])][a.parts - 1 :: a.parts]
     fwd = []
     prev = -1
     for e in ends:
@@ -100,7 +105,7 @@ def main():
                 agg[fam] += float(r["Counter_Value"])
                 cnt[fam] += 1
             tot[kind] = (agg, cnt)
-        nf = len([1 for r in load(os.path.join(a.fetch, "*_counter_collection.csv")) if "global_avgpool" in r["Kernel_Name"]]) // a.parts
+        nf = len([1 for r in load(os.path.join(a.fetch, "*_counter_collection.csv")) if forward_end(r["Kernel_Name"])]) // a.parts
         out.append("\n## HBM traffic (PMC, separate passes, %d forwards each)\n\n" % nf)
         out.append("| family | FETCH_SIZE KB/forward | x2 (gfx950 fetch correction) GB | WRITE_SIZE KB/forward | GB |\n|---|---:|---:|---:|---:|\n")
         res = {}

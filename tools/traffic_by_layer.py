@@ -62,7 +62,8 @@ def per_dispatch(d):
 def last_forward(rows, parts=2):
     """Per conv of the plan: [counter KB, ns, kernel] summed over the stream parts of the last forward (dispatch ids follow
     launch order: part 0's whole chain, then part 1's)."""
-    ends = [i for i, r in enumerate(rows) if "global_avgpool" in r["Kernel_Name"]]
+    # (a forward ends in global_avgpool, or in the conv whose epilogue takes the mean: EPI_AVG = 6)
+    ends = [i for i, r in enumerate(rows) if "global_avgpool" in r["Kernel_Name"] or "conv3d_igemm_dma_kernel<128, 64, 16, false, 2, 6," in r["Kernel_Name"]]
     total = None
     for p in range(parts):
         e = len(ends) - parts + p
