@@ -77,6 +77,10 @@ class ConvEpilogue(C.Structure):
                 + [("avgpool_out", C.c_void_p)])
 
 
+class NtItem(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("A", "B", "C", "rowsum")] + [("M", C.c_int32), ("N", C.c_int32), ("lda", C.c_int64), ("ldb", C.c_int64)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ("M", "N", "K", "batch")]
                 + [(n, C.c_int64) for n in ("sAb", "sAm", "sAk", "sBb", "sBk", "sBn", "sCb", "sCm", "sCn")]
@@ -121,6 +125,7 @@ SIGNATURES = {
     "advhip_gemm_nt_reduced_f32": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _I, _P, _L, _P]),
     "advhip_gemm_nt_slabs_f32": (C.c_int, [_P, _P, _P, _I, _I, _I, _L, _L, _I, _I, _I, _P]),
     "advhip_sum_slabs_f32": (C.c_int, [_P, _P, _L, _I, _L, _P]),
+    "advhip_gemm_nt_group_slabs_f32": (C.c_int, [C.POINTER(NtItem), _I, _I, _I, _L, _P]),
     "advhip_softmax_rows_f32": (C.c_int, [_P, _P, _L, _I, C.c_float, _P]),
     "advhip_conv3d_bn_act_ex_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _L, _P, _P, _P, _P, _P, _P, _L, C.POINTER(ConvEpilogue), _P, _L, _P]),
     "advhip_chan_stats_f32": (C.c_int, [_P, _P, _P, _I, _L, C.c_float, _P]),

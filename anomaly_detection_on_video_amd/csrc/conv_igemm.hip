@@ -1620,7 +1620,7 @@ struct GemmKKArgs {
 // (the small layers' weight gradients: few output tiles, K = 10 240) measured no gain -- those launches are bound by the
 // latency chain of their slice sums and launch gaps, not by the ring (profiles/r03_gemm_nt_tune.txt).
 template <int BM, int BN, int NS = 2>
-__global__ __launch_bounds__(256) void gemm_kk_dma_kernel(const GemmKKArgs g) {
+__device__ __forceinline__ void gemm_kk_body(const GemmKKArgs& g, const int block) {
   constexpr int BK = 16, FM = BM / 32, FN = BN / 32;
   static_assert(NS >= 2 && NS <= 8, "ring depth");
   constexpr int STAGE = (BM + BN) * BK;  // floats
@@ -1638,7 +1638,7 @@ __global__ __launch_bounds__(256) void gemm_kk_dma_kernel(const GemmKKArgs g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntiles = g.tiles_m * g.tiles_n;
-  const int it = xcd_remap((int)blockIdx.x, ntiles * g.splits);
+  const int it = xcd_remap(block, ntiles * g.splits);
   const int L = it / g.splits, split = it - L * g.splits;
   const int tile_m = L / g.tiles_n, tile_n = L - tile_m * g.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -1828,6 +1828,47 @@ __global__ __launch_bounds__(256) void gemm_kk_dma_kernel(const GemmKKArgs g) {
         if (n < g.N) C[(long long)m * g.ldc + n] = acc[i][j][r];
       }
     }
+}
+
+template <int BM, int BN, int NS = 2>
+__global__ __launch_bounds__(256) void gemm_kk_dma_kernel(const GemmKKArgs g) {
+  gemm_kk_body<BM, BN, NS>(g, (int)blockIdx.x);
+}
+
+// Several small NT products (K slices to slabs) in ONE launch: the weight gradients of the 64- and 128-channel layers are a
+// handful of 64 x 64 tiles each, ~12 us of latency chain per launch and a launch gap on either side -- 31 of them per MGFN
+// training step.  Items travel in the kernel arguments (no table in device memory: the launch is graph-capturable as is);
+// workgroup b works on the item whose range [wg_begin, next wg_begin) holds it, exactly as gemm_kk_dma_kernel<64, 64> would.
+constexpr int NT_GROUP_MAX = 32;
+struct NtGroupItem {
+  const float* A;
+  const float* B;
+  float* C;
+  float* rowsum;  // nullable
+  int M, N, lda, ldb;
+  unsigned a_bytes, b_bytes;
+  int tiles_n, wg_begin;
+};
+struct NtGroupArgs {
+  NtGroupItem it[NT_GROUP_MAX];
+  int n, K, splits, pad;
+  long long slab;  // elements between the outputs (and row sums) of consecutive K slices: one slab matrix for all items
+};
+
+__global__ __launch_bounds__(256) void gemm_kk_group_kernel(const NtGroupArgs ga) {
+  int i = 0;
+  while (i + 1 < ga.n && (int)blockIdx.x >= ga.it[i + 1].wg_begin) ++i;  // (uniform: scalar loads from the kernel arguments)
+  const NtGroupItem& t = ga.it[i];
+  GemmKKArgs g;
+  g.A = t.A; g.B = t.B; g.C = t.C;
+  g.M = t.M; g.N = t.N; g.K = ga.K;
+  g.lda = t.lda; g.ldb = t.ldb; g.ldc = t.N;
+  g.a_bytes = t.a_bytes; g.b_bytes = t.b_bytes;
+  g.tiles_m = (t.M + 63) / 64; g.tiles_n = t.tiles_n; g.splits = ga.splits;
+  g.slab = ga.slab;
+  g.rowsum = t.rowsum; g.rs_slab = ga.slab;
+  g.part = nullptr; g.cnt = nullptr; g.part_bytes = 0;
+  gemm_kk_body<64, 64, 2>(g, (int)blockIdx.x - t.wg_begin);
 }
 
 // ================================================================================================
@@ -3203,6 +3244,39 @@ extern "C" int advhip_gemm_nt_slabs_f32(const float* A, const float* B, float* s
   const long long stride = (long long)M * N + (with_rowsum ? M : 0);
   return advhip::gemm_nt_launch(A, B, slabs, M, N, K, lda, ldb, N, splits, stride, tile, with_rowsum ? slabs + (long long)M * N : nullptr,
                                 nullptr, 0, stream, stride);
+}
+
+extern "C" int advhip_gemm_nt_group_slabs_f32(const advhip_nt_item* items, int32_t n_items, int32_t K, int32_t splits, int64_t slab_stride,
+                                              void* stream) {
+  using namespace advhip;
+  ADVHIP_REQUIRE(items && n_items > 0 && K > 0 && K % 16 == 0 && splits >= 1 && splits <= K / 16, "gemm_nt_group: bad arguments (K=%d, splits=%d)", K, splits);
+  for (int base = 0; base < n_items; base += NT_GROUP_MAX) {
+    NtGroupArgs ga;
+    ga.n = std::min(NT_GROUP_MAX, n_items - base);
+    ga.K = K; ga.splits = splits; ga.pad = 0; ga.slab = slab_stride;
+    long long wg = 0;
+    for (int i = 0; i < ga.n; ++i) {
+      const advhip_nt_item& s = items[base + i];
+      ADVHIP_REQUIRE(s.A && s.B && s.C && s.M > 0 && s.N > 0, "gemm_nt_group: item %d: bad arguments", base + i);
+      ADVHIP_REQUIRE(s.lda % 4 == 0 && s.ldb % 4 == 0 && s.lda >= K && s.ldb >= K && ((uintptr_t)s.A & 15) == 0 && ((uintptr_t)s.B & 15) == 0,
+                     "gemm_nt_group: item %d: operands must be 16-byte aligned with row pitches that are multiples of 4 and >= K", base + i);
+      const long long a_bytes = ((long long)(s.M - 1) * s.lda + K) * 4, b_bytes = ((long long)(s.N - 1) * s.ldb + K) * 4;
+      ADVHIP_REQUIRE(a_bytes < 0xF0000000ll && b_bytes < 0xF0000000ll && s.lda < (1ll << 31) && s.ldb < (1ll << 31), "gemm_nt_group: item %d: operand above 3.75 GiB", base + i);
+      ADVHIP_REQUIRE(slab_stride >= (long long)s.M * s.N, "gemm_nt_group: slab stride smaller than item %d's output", base + i);
+      NtGroupItem& t = ga.it[i];
+      t.A = s.A; t.B = s.B; t.C = s.C; t.rowsum = s.rowsum;
+      t.M = s.M; t.N = s.N; t.lda = (int)s.lda; t.ldb = (int)s.ldb;
+      t.a_bytes = (unsigned)a_bytes; t.b_bytes = (unsigned)b_bytes;
+      t.tiles_n = (s.N + 63) / 64;
+      t.wg_begin = (int)wg;
+      wg += (long long)((s.M + 63) / 64) * t.tiles_n * splits;
+      ADVHIP_REQUIRE(wg < (1ll << 31), "gemm_nt_group: too many tiles");
+    }
+    for (int i = ga.n; i < NT_GROUP_MAX; ++i) ga.it[i] = NtGroupItem{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0u, 0u, 0, 0x7FFFFFFF};
+    hipLaunchKernelGGL(gemm_kk_group_kernel, dim3((unsigned)wg), dim3(256), 0, (hipStream_t)stream, ga);
+    if (int rc = check_launch("gemm_nt_group")) return rc;
+  }
+  return ADVHIP_OK;
 }
 
 extern "C" int advhip_sum_slabs_f32(const float* slabs, float* out, int64_t n, int32_t splits, int64_t stride, void* stream) {

@@ -346,6 +346,68 @@ class _Fork:
         return False
 
 
+# ---- weight / bias gradients of the narrow layers, all in one launch at the end of the backward pass ----------------------------
+# dW = dY X^T of a 64- or 128-channel layer is a handful of 64 x 64 tiles over K = all positions: ~12 us of latency chain, a reduce
+# launch and two launch gaps each, 31 layers per step (~1 ms of a 16-ms step).  Inside `deferred_param_grads()` the backward
+# functions below do not compute them: they return None for those parameters, keep (dY, X) alive, and a callback queued on the
+# autograd engine runs ONE grouped launch + ONE reduce when the backward pass is over and puts the results where autograd's
+# AccumulateGrad would have (param.grad = g, or += g).  Same kernels, slices and summation order as the per-layer launches: the
+# same bits.  Opt-in because only `.backward()` sees these gradients -- `torch.autograd.grad` and parameter hooks do not; the
+# trainer's step (train_graph.GraphedTrainStep, runner.Trainer) turns it on.
+_DEFER = {"on": False, "items": [], "queued": False}
+DEFER_DW = os.environ.get("ADV_MGFN_DEFER_DW", "1") == "1"  # what the trainer's step passes to deferred_param_grads
+
+
+class deferred_param_grads:
+    def __init__(self, enabled: bool = True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        self.prev = _DEFER["on"]
+        _DEFER["on"] = bool(self.enabled)
+        return self
+
+    def __exit__(self, *exc):
+        _DEFER["on"] = self.prev
+        if _DEFER["items"]:  # (a backward pass that never finished: drop what it left)
+            _DEFER["items"].clear()
+            _DEFER["queued"] = False
+        return False
+
+
+def _flush_deferred() -> None:
+    items, _DEFER["items"], _DEFER["queued"] = _DEFER["items"], [], False
+    if not items:
+        return
+    by_k = {}
+    for it in items:  # (one launch per distinct K and device: one, in an MGFN step)
+        by_k.setdefault((it[0].shape[1], it[0].device), []).append(it)
+    with torch.no_grad():
+        for group in by_k.values():
+            with torch.cuda.device(group[0][0].device):
+                outs = ops.gemm_nt_group([(g2, x2, bp is not None) for g2, x2, _wp, bp in group])
+            for (g2, x2, wp, bp), (dw, db) in zip(group, outs):
+                for p, g in ((wp, dw.view(wp.shape)), (bp, db)):
+                    if p is None:
+                        continue
+                    if p.grad is None:
+                        p.grad = g
+                    else:
+                        p.grad.add_(g)
+
+
+def _defer_dw(g2: torch.Tensor, x2: torch.Tensor, wparam, bparam) -> bool:
+    """Queue dW = g2 x2^T (and db = rowsum(g2) when `bparam` is given) for the grouped launch; False = compute it now."""
+    if not (_DEFER["on"] and wparam is not None and ops.gemm_nt_is_small(g2.shape[0], x2.shape[0]) and g2.shape[1] % 256 == 0
+            and g2.is_contiguous() and x2.is_contiguous()):
+        return False
+    _DEFER["items"].append((g2, x2, wparam, bparam))
+    if not _DEFER["queued"]:
+        _DEFER["queued"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
+    return True
+
+
 # k = 3 layers as plain GEMMs on unfolded operands (K3_AS_GEMM): the im2col-free k = 3 conv gathers 4-byte pieces (its taps shift
 # positions inside a row of T, with zero padding at the row ends, so 16-byte pieces are out) and runs 110-116 TFLOP/s; the
 # same contraction as a 1x1 GEMM over U = unfold3(x) (3 Cin rows, one 126-MB pass at stage 2) takes the 16-byte operand path at
@@ -370,6 +432,7 @@ class _LinearCN(torch.autograd.Function):
             y = conv_cn(x, pack_kc_cached(weight, fresh), cout, k, shift=shift, residual=res)
             ctx.save_for_backward(x, weight)
         ctx.unfolded = unfolded
+        ctx.params = (weight, bias)  # (the parameters themselves: deferred_param_grads writes their .grad at the end of the pass)
         ctx.dx_pack = _step_dx(weight) if k > 1 and fresh else None  # (packed with this forward's other operands: step_packs)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         # y = conv(x) + x (the blocks' `x = scc(x) + x`): dL/dx = conv^T(dy) + dy comes out of ONE launch (dy as the dX GEMM's
@@ -401,9 +464,12 @@ class _LinearCN(torch.autograd.Function):
                     xk = x.detach().view(cin, -1)
                 else:
                     xk = x.view(3 * cin, -1) if ctx.unfolded else _unfold3(x.detach())
-                res = ops.gemm_nt(dy.view(cout, -1), xk, rowsum=want_db)
-                dw, db = res if want_db else (res, None)
-                dw = dw.view(cout, cin, k)
+                if _defer_dw(dy.view(cout, -1), xk, ctx.params[0], ctx.params[1] if want_db else None):
+                    dw = db = None
+                else:
+                    res = ops.gemm_nt(dy.view(cout, -1), xk, rowsum=want_db)
+                    dw, db = res if want_db else (res, None)
+                    dw = dw.view(cout, cin, k)
             elif want_db:
                 db = dy.sum(dim=(1, 2))
             fk.out(dw, db)
@@ -424,6 +490,7 @@ class _FFNCN(torch.autograd.Function):
         y = conv_cn(h, pack_kc_cached(w2, fresh), dim, 1, shift=b2.detach(), residual=x_res.detach().contiguous())
         if need_z:
             ctx.save_for_backward(xh, z, h, w1, w2)
+        ctx.params = (w1, b1, w2, b2)
         return y
 
     @staticmethod
@@ -431,27 +498,24 @@ class _FFNCN(torch.autograd.Function):
         xh, z, h, w1, w2 = ctx.saved_tensors
         hid, dim = w1.shape[0], w1.shape[1]
         dy = dy.contiguous()
-        def dw_db(g, act, want_w, want_b):  # dW = g act^T (+ db = rowsum(g) out of the same launch)
-            if want_w:
-                res = ops.gemm_nt(g.view(g.shape[0], -1), act.view(act.shape[0], -1), rowsum=want_b)
-                w, b = res if want_b else (res, None)
-                return w.view(g.shape[0], act.shape[0], 1), b
-            return None, (g.sum(dim=(1, 2)) if want_b else None)
-
+        w1p, b1p, w2p, b2p = ctx.params
         with _Fork(dy, h) as fk:
-            dw2, db2 = dw_db(dy, h, ctx.needs_input_grad[4], ctx.needs_input_grad[5])
+            dw2, db2 = _dw_db(dy, h, ctx.needs_input_grad[4], ctx.needs_input_grad[5], w2p, b2p)
             fk.out(dw2, db2)
         dz = conv_cn(dy, w2.detach().view(dim, hid), hid, 1, dact_z=z)          # (W2^T dY) * GELU'(z)
         with _Fork(dz, xh) as fk:
-            dw1, db1 = dw_db(dz, xh.detach(), ctx.needs_input_grad[2], ctx.needs_input_grad[3])
+            dw1, db1 = _dw_db(dz, xh.detach(), ctx.needs_input_grad[2], ctx.needs_input_grad[3], w1p, b1p)
             fk.out(dw1, db1)
         dxh = conv_cn(dz, w1.detach().view(hid, dim), dim, 1) if ctx.needs_input_grad[0] else None
         return dxh, (dy if ctx.needs_input_grad[1] else None), dw1, db1, dw2, db2, None
 
 
-def _dw_db(g: torch.Tensor, act: torch.Tensor, want_w: bool, want_b: bool):
-    """dW = g act^T over the positions (1x1 layer), and db = rowsum(g) out of the same launch."""
+def _dw_db(g: torch.Tensor, act: torch.Tensor, want_w: bool, want_b: bool, wparam=None, bparam=None):
+    """dW = g act^T over the positions (1x1 layer), and db = rowsum(g) out of the same launch -- or (None, None) when the pair was
+    queued for the grouped launch at the end of the backward pass (deferred_param_grads; `wparam` / `bparam`: the parameters)."""
     if want_w:
+        if _defer_dw(g.view(g.shape[0], -1), act.view(act.shape[0], -1), wparam, bparam if want_b else None):
+            return None, None
         res = ops.gemm_nt(g.view(g.shape[0], -1), act.view(act.shape[0], -1), rowsum=want_b)
         w, b = res if want_b else (res, None)
         return w.view(g.shape[0], act.shape[0], 1), b
@@ -479,6 +543,7 @@ class _FFNBlockCN(torch.autograd.Function):
         h, z = conv_cn(xh, pack_kc_cached(w1, fresh), hid, 1, shift=b1.detach(), act=ACT_GELU, want_preact=True)
         y = conv_cn(h, pack_kc_cached(w2, fresh), c, 1, shift=b2.detach(), residual=x)
         ctx.save_for_backward(x, gf, mu, rs, xh, z, h, w1, w2)
+        ctx.params = (w1, b1, w2, b2)
         ctx.eps, ctx.gshape = eps, g.shape
         return y
 
@@ -489,9 +554,10 @@ class _FFNBlockCN(torch.autograd.Function):
         n = x.numel() // dim
         need = ctx.needs_input_grad
         dy = dy.contiguous()
-        dw2, db2 = _dw_db(dy, h, need[6], need[7])
+        w1p, b1p, w2p, b2p = ctx.params
+        dw2, db2 = _dw_db(dy, h, need[6], need[7], w2p, b2p)
         dz = conv_cn(dy, w2.detach().view(dim, hid), hid, 1, dact_z=z)          # (W2^T dY) * GELU'(z)
-        dw1, db1 = _dw_db(dz, xh, need[4], need[5])
+        dw1, db1 = _dw_db(dz, xh, need[4], need[5], w1p, b1p)
         dxh = conv_cn(dz, w1.detach().view(hid, dim), dim, 1)
         lib = _lib.load()
         rows = lib.advhip_chan_layernorm_bwd_partial_rows(n)
@@ -543,6 +609,7 @@ class _FocusAttnBlockCN(torch.autograd.Function):
         check(lib.advhip_dwconv_t_fwd_f32(ptr(v), ptr(w2), ptr(brel.detach().contiguous()), ptr(o), inner, heads, b_, t, k, stream(x)), "dwconv_t_fwd")
         y = conv_cn(o, pack_kc_cached(wo, fresh), c, 1, shift=bo.detach(), residual=x)
         ctx.save_for_backward(x, bn_w, mean, var, xb, v, w2, o, wv, wo)
+        ctx.params = (wv, wo, bo)
         ctx.eps, ctx.heads, ctx.wrel_shape = bn.eps, heads, wrel.shape
         return y
 
@@ -555,14 +622,15 @@ class _FocusAttnBlockCN(torch.autograd.Function):
         need = ctx.needs_input_grad
         lib = _lib.load()
         dy = dy.contiguous()
-        dwo, dbo = _dw_db(dy, o, need[6], need[7])
+        wvp, wop, bop = ctx.params
+        dwo, dbo = _dw_db(dy, o, need[6], need[7], wop, bop)
         do = conv_cn(dy, wo.detach().view(c, inner), inner, 1)
         chunks = lib.advhip_dwconv_t_bwd_chunks(inner, b_)
         dv = torch.empty_like(v)
         partial = torch.empty((inner * chunks, k + 1), device=x.device, dtype=torch.float32)
         check(lib.advhip_dwconv_t_bwd_f32(ptr(do), ptr(v), ptr(w2), ptr(dv), ptr(partial), inner, heads, b_, t, k, stream(x)), "dwconv_t_bwd")
         per_head = colsum(partial.view(inner // heads * chunks, heads * (k + 1))).view(heads, k + 1)  # rows = (c_idx, chunk)
-        dwv, _ = _dw_db(dv, xb, need[3], False)
+        dwv, _ = _dw_db(dv, xb, need[3], False, wvp, None)
         dxb = conv_cn(dv, wv.detach().view(inner, c), c, 1)
         dx = torch.empty_like(x)
         dg = torch.empty((c,), device=x.device, dtype=torch.float32)

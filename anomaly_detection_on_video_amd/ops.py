@@ -626,7 +626,52 @@ def gemm_nt_choice(M: int, N: int, K: int) -> Tuple[int, int]:
     if hit is not None:
         return hit
     tiles = -(-M // 64) * -(-N // 64)
-    return 0, max(1, min(64, 1024 // max(tiles, 1), K // 256))  # few output tiles (128-channel layers): many K slices
+    if tiles < 64:  # few output tiles (the 64- / 128-channel layers): 16 K slices to slabs measured best for every such shape
+        return 1, max(1, min(NT_SMALL_SPLITS, K // 256))  # (profiles/r03_gemm_nt_tune.txt: 32-35 us vs 36-58 for 40)
+    return 0, max(1, min(64, 1024 // max(tiles, 1), K // 256))
+
+
+NT_SMALL_SPLITS = 16
+
+
+def gemm_nt_is_small(M: int, N: int) -> bool:
+    """gemm_nt takes the slab + one-reduce form for this output (a handful of 64 x 64 tiles): what gemm_nt_group batches."""
+    return -(-M // 64) * -(-N // 64) < 64
+
+
+def gemm_nt_group(items):
+    """[(a (M,K), b (N,K), rowsum: bool), ...] -> [(a @ b^T, row sums of a or None), ...]: every small product of the list in ONE
+    launch (K slices to one slab matrix) + ONE reduce launch (include/advhip.h: advhip_gemm_nt_group_slabs_f32) -- bit for bit what
+    gemm_nt returns for each of them alone.  All items contract over the same K."""
+    if not items:
+        return []
+    K = items[0][0].shape[1]
+    dev = items[0][0].device
+    offs, total = [], 0
+    for a, b, rs in items:
+        require_gpu(a, b, contiguous=False)
+        if a.dim() != 2 or b.dim() != 2 or a.shape[1] != K or b.shape[1] != K or a.stride(1) != 1 or b.stride(1) != 1:
+            raise ValueError(f"gemm_nt_group: need (M,K) and (N,K) operands over one K = {K} with unit inner stride, got {tuple(a.shape)} / {tuple(b.shape)}")
+        offs.append(total)
+        total += -(-(a.shape[0] * b.shape[0] + (a.shape[0] if rs else 0)) // 64) * 64
+    splits = max(1, min(NT_SMALL_SPLITS, K // 256))
+    slabs = torch.empty((splits, total), device=dev, dtype=torch.float32)
+    res = torch.empty((total,), device=dev, dtype=torch.float32)
+    arr = (_lib.NtItem * len(items))()
+    base = slabs.data_ptr()
+    for it, (a, b, rs), off in zip(arr, items, offs):
+        M, N = a.shape[0], b.shape[0]
+        it.A, it.B, it.C = a.data_ptr(), b.data_ptr(), base + off * 4
+        it.rowsum = base + (off + M * N) * 4 if rs else None
+        it.M, it.N, it.lda, it.ldb = M, N, a.stride(0), b.stride(0)
+    lib = _lib.load()
+    check(lib.advhip_gemm_nt_group_slabs_f32(arr, len(items), K, splits, total, stream(dev)), "gemm_nt_group")
+    check(lib.advhip_sum_slabs_f32(ptr(slabs), ptr(res), total, splits, total, stream(dev)), "sum_slabs")
+    out = []
+    for (a, b, rs), off in zip(items, offs):
+        M, N = a.shape[0], b.shape[0]
+        out.append((res[off : off + M * N].view(M, N), res[off + M * N : off + M * N + M] if rs else None))
+    return out
 
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, splits: int = 0, rowsum: bool = False, tile: int = 0,

@@ -52,7 +52,8 @@ class GraphedTrainStep:
 
     def _step(self, video, al, nl) -> torch.Tensor:
         self.optimizer.zero_grad(set_to_none=True)
-        with mgfn_ops.overlapped_backward(self.overlap):
+        # (the narrow layers' weight / bias gradients: one grouped launch at the end of the backward pass, ADV_MGFN_DEFER_DW=0: per layer)
+        with mgfn_ops.overlapped_backward(self.overlap), mgfn_ops.deferred_param_grads(mgfn_ops.DEFER_DW):
             loss = self.model(video=video, abnormal_labels=al, normal_labels=nl).loss
             loss.backward()
         if self.clip:

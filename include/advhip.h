@@ -333,6 +333,21 @@ int advhip_gemm_nt_reduced_f32(const float* A, const float* B, float* C, float* 
 int advhip_gemm_nt_slabs_f32(const float* A, const float* B, float* slabs, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb,
                              int32_t splits, int32_t tile, int32_t with_rowsum, void* stream);
 int advhip_sum_slabs_f32(const float* slabs, float* out, int64_t n, int32_t splits, int64_t stride, void* stream);
+/* Many such products in ONE launch: item i writes slice s of A_i B_i^T (64 x 64 tiles, as advhip_gemm_nt_slabs_f32 with tile 1) to
+ * C_i + s * slab_stride (row pitch N_i) and, when rowsum_i is given, the slice's row sums of A_i to rowsum_i + s * slab_stride;
+ * all items contract over the same K in the same number of slices.  With C_i / rowsum_i laid out back to back inside one
+ * [splits][slab_stride] matrix, ONE advhip_sum_slabs_f32 reduces every product and every row sum.  `items` is a HOST array (it
+ * travels in the kernel arguments, 32 items per launch): the weight and bias gradients of all narrow layers of an MGFN training
+ * step (autograd of nn.Conv1d, modeling_mgfn.py:49-64,101-108,150-193) at the end of the backward pass. */
+typedef struct advhip_nt_item {
+  const float* A;  /* (M, K), row pitch lda */
+  const float* B;  /* (N, K), row pitch ldb */
+  float* C;
+  float* rowsum;   /* nullable */
+  int32_t M, N;
+  int64_t lda, ldb;
+} advhip_nt_item;
+int advhip_gemm_nt_group_slabs_f32(const advhip_nt_item* items, int32_t n_items, int32_t K, int32_t splits, int64_t slab_stride, void* stream);
 
 /* y[r, :] = softmax(x[r, :] * scale) over rows of n contiguous floats (F.softmax(theta_phi * dim_inner**-0.5, dim=-1),
  * src/i3d.py:174-175; the attention softmax of GlanceAttention, modeling_mgfn.py:115-120).  x == y allowed. */

@@ -465,3 +465,28 @@ def test_step_packs_equal_the_per_layer_packs_and_are_used_inside_one_forward():
         mgfn_ops.end_step_packs()
     fresh = mgfn_ops.pack_kc_cached(convs[0].weight, fresh=True)  # outside a forward: packed on the spot
     assert fresh.data_ptr() != first.data_ptr() and mgfn_ops._step_dx(convs[1].weight) is None
+
+
+def test_gemm_nt_group_equals_the_single_launches():
+    """advhip_gemm_nt_group_slabs_f32 + one advhip_sum_slabs_f32: 40 small NT products (more than one kernel-argument block of
+    32) with and without row sums, ragged M / N, bit for bit what gemm_nt returns for each alone; and vs fp64."""
+    from anomaly_detection_on_video_amd import ops
+
+    K = 2560
+    shapes = [(64, 64), (128, 128), (128, 384), (512, 128), (64, 192), (96, 40), (128, 512), (200, 72)] * 5
+    items = []
+    for i, (m, n) in enumerate(shapes):
+        a = synth_tensor(f"ntg.a{i}", (m, K)).to(DEV)
+        b = synth_tensor(f"ntg.b{i}", (n, K)).to(DEV)
+        items.append((a, b, i % 3 != 0))
+    outs = ops.gemm_nt_group(items)
+    assert len(outs) == len(items)
+    for (a, b, rs), (c, r) in zip(items, outs):
+        assert ops.gemm_nt_is_small(a.shape[0], b.shape[0])
+        single = ops.gemm_nt(a, b, rowsum=rs)
+        c1, r1 = single if rs else (single, None)
+        assert torch.equal(c, c1)
+        assert (r is None) == (not rs) and (r is None or torch.equal(r, r1))
+        assert rel_err(c.cpu().double(), a.cpu().double() @ b.cpu().double().t()) < 1e-5
+    with pytest.raises(ValueError):
+        ops.gemm_nt_group([(items[0][0], items[1][1][:, :1280], False)])

@@ -111,3 +111,38 @@ def test_the_step_ran_on_the_benchmarked_kernels(step_records):
     # weight gradients dW = dY X^T: contraction over all 10 240 positions, stage-2 shapes present
     assert nts and all(kk == n for _a, _b, kk in nts), nts[:4]
     assert (4096, 1024, n) in nts and (1024, 4096, n) in nts and (1024, 3072, n) in nts
+
+
+def test_deferred_param_grads_equal_the_per_layer_launches(step_records):
+    """mgfn_ops.deferred_param_grads (what GraphedTrainStep turns on): the narrow layers' weight / bias gradients from ONE
+    grouped launch at the end of the backward pass, written to .grad by the engine callback -- bit for bit the gradients of the
+    per-layer launches, for all 130 parameters, at the benchmarked shape; a second pass accumulates (+=) as autograd does."""
+    from anomaly_detection_on_video_amd import mgfn_ops, ops
+
+    model, _o, _r, _p, _d, _n = step_records
+    want = {k: p.grad.clone() for k, p in model.named_parameters()}
+    video = bench_shape_video().to(DEV)
+    nl, al = torch.zeros(BS // 2, device=DEV), torch.ones(BS // 2, device=DEV)
+    calls = []
+    orig = ops.gemm_nt_group
+    ops.gemm_nt_group = lambda items: (calls.append(len(items)), orig(items))[1]
+    try:
+        for passes in (1, 2):
+            for p in model.parameters():
+                p.grad = None
+            for _ in range(passes):
+                with mgfn_ops.deferred_param_grads():
+                    model(video=video, abnormal_labels=al, normal_labels=nl).loss.backward()
+            torch.cuda.synchronize()
+            for k, p in model.named_parameters():
+                assert p.grad is not None, k
+                if passes == 1:
+                    assert torch.equal(p.grad, want[k]), (k, float((p.grad - want[k]).abs().max()))
+                else:
+                    assert rel_err(p.grad.cpu(), (2 * want[k]).cpu()) < 1e-6, k
+    finally:
+        ops.gemm_nt_group = orig
+        for k, p in model.named_parameters():
+            p.grad = want[k]
+    assert calls and all(c >= 25 for c in calls), calls  # one grouped launch per backward pass, ~31 layers in it
+    assert not mgfn_ops._DEFER["items"] and not mgfn_ops._DEFER["queued"] and not mgfn_ops._DEFER["on"]
