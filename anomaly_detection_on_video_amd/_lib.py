@@ -77,6 +77,10 @@ class ConvEpilogue(C.Structure):
                 + [("avgpool_out", C.c_void_p)])
 
 
+class ColsumItem(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int32), ("period", C.c_int32)]
+
+
 class NtItem(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("A", "B", "C", "rowsum")] + [("M", C.c_int32), ("N", C.c_int32), ("lda", C.c_int64), ("ldb", C.c_int64)]
 
@@ -143,6 +147,7 @@ SIGNATURES = {
     "advhip_chan_layernorm_bwd_add_f32": (C.c_int, [_P] * 8 + [_I, _L, C.c_float, _P]),
     "advhip_conv1d_pack_weight_dx_f32": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "advhip_colsum_f32": (C.c_int, [_P, _P, _L, _I, _P]),
+    "advhip_colsum_group_f32": (C.c_int, [C.POINTER(ColsumItem), _I, _P]),
     "advhip_pack_item_tiles": (C.c_int64, [_I, _I, _I, _I]),
     "advhip_pack_weights_multi_f32": (C.c_int, [_P, _I, _I, _P]),
     "advhip_unfold3_f32": (C.c_int, [_P, _P, _I, _L, _I, _P]),

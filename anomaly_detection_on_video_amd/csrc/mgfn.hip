@@ -335,10 +335,13 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_kernel(const float* __restric
 // four parameter gradients, the depth-wise conv's filter gradients): 32 columns x 8 row groups per block, each thread walks its
 // rows eight loads at a time, the row groups are added in fixed order through LDS.  torch's generic reduction takes 10-20 us on
 // these few-hundred-row matrices; 26 of them per training step.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ src, float* __restrict__ dst, long long rows, int cols) {
+// `period` > 0: the columns are [cols / period groups][period] and the sums leave de-interleaved -- element j < period - 1 of group h to
+// dst[h * (period - 1) + j], the last element of every group to dst[(cols / period) * (period - 1) + h] (the depth-wise conv's per-head
+// (filter taps | bias) sums -> the filter gradient, then the bias gradient, each contiguous)
+__device__ __forceinline__ void colsum_body(const float* __restrict__ src, float* __restrict__ dst, long long rows, int cols, int block, int period) {
   __shared__ float part[8][33];
   const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  const int c = block * 32 + cl;
   float acc = 0.f;
   if (c < cols) {
     long long r = grp;
@@ -357,8 +360,36 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ s
     float t = part[0][cl];
 #pragma unroll
     for (int gI = 1; gI < 8; ++gI) t += part[gI][cl];
-    dst[c] = t;
+    if (period > 0) {
+      const int h = c / period, j = c - h * period;
+      dst[j < period - 1 ? h * (period - 1) + j : (cols / period) * (period - 1) + h] = t;
+    } else {
+      dst[c] = t;
+    }
   }
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ src, float* __restrict__ dst, long long rows, int cols) {
+  colsum_body(src, dst, rows, cols, (int)blockIdx.x, 0);
+}
+
+// Many such matrices in one launch (items in the kernel arguments): every partial-sum matrix a backward pass left behind, at its end.
+constexpr int COLSUM_GROUP_MAX = 64;
+struct ColsumGroupItem {
+  const float* src;
+  float* dst;
+  long long rows;
+  int cols, block_begin, period, pad;
+};
+struct ColsumGroupArgs {
+  ColsumGroupItem it[COLSUM_GROUP_MAX];
+  int n;
+};
+__global__ __launch_bounds__(256) void colsum_group_kernel(const ColsumGroupArgs ga) {
+  int i = 0;
+  while (i + 1 < ga.n && (int)blockIdx.x >= ga.it[i + 1].block_begin) ++i;
+  const ColsumGroupItem& t = ga.it[i];
+  colsum_body(t.src, t.dst, t.rows, t.cols, (int)blockIdx.x - t.block_begin, t.period);
 }
 
 // ---- the scorer's head on the body's layout (modeling_mgfn.py:387-389: permute -> nn.LayerNorm(C) -> Linear(C, 1) -> sigmoid) ----
@@ -848,4 +879,25 @@ extern "C" int advhip_pack_weights_multi_f32(const advhip_pack_item* items_dev, 
   ADVHIP_REQUIRE(items_dev && n_items > 0 && n_tiles > 0, "pack_weights_multi: bad arguments");
   hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)std::min(n_tiles, 256 * 64)), dim3(256), 0, (hipStream_t)stream, items_dev, n_items, n_tiles);
   return check_launch("pack_weights_multi");
+}
+
+extern "C" int advhip_colsum_group_f32(const advhip_colsum_item* items, int32_t n_items, void* stream) {
+  ADVHIP_REQUIRE(items && n_items > 0, "colsum_group: bad arguments");
+  for (int base = 0; base < n_items; base += COLSUM_GROUP_MAX) {
+    ColsumGroupArgs ga;
+    ga.n = std::min(COLSUM_GROUP_MAX, n_items - base);
+    long long blocks = 0;
+    for (int i = 0; i < ga.n; ++i) {
+      const advhip_colsum_item& s = items[base + i];
+      ADVHIP_REQUIRE(s.src && s.dst && s.rows > 0 && s.cols > 0 && s.period >= 0 && (s.period == 0 || (s.period >= 2 && s.cols % s.period == 0)),
+                     "colsum_group: item %d: bad arguments", base + i);
+      ga.it[i] = ColsumGroupItem{s.src, s.dst, (long long)s.rows, s.cols, (int)blocks, s.period, 0};
+      blocks += (s.cols + 31) / 32;
+      ADVHIP_REQUIRE(blocks < (1ll << 31), "colsum_group: too many columns");
+    }
+    for (int i = ga.n; i < COLSUM_GROUP_MAX; ++i) ga.it[i] = ColsumGroupItem{nullptr, nullptr, 0, 0, 0x7FFFFFFF, 0, 0};
+    hipLaunchKernelGGL(colsum_group_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ga);
+    if (int rc = check_launch("colsum_group")) return rc;
+  }
+  return ADVHIP_OK;
 }

@@ -251,6 +251,25 @@ def colsum(partial: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def colsum_group(items):
+    """[(partial (rows, cols), period), ...] -> [column sums (cols,), ...] of all of them in ONE launch (include/advhip.h:
+    advhip_colsum_group_f32; period > 0: de-interleaved, see there).  The results are slices of one buffer."""
+    if not items:
+        return []
+    dev = items[0][0].device
+    offs, total = [], 0
+    for part, _period in items:
+        _lib.require_gpu(part)
+        offs.append(total)
+        total += -(-part.shape[1] // 64) * 64
+    res = torch.empty((total,), device=dev, dtype=torch.float32)
+    arr = (_lib.ColsumItem * len(items))()
+    for it, (part, period), off in zip(arr, items, offs):
+        it.src, it.dst, it.rows, it.cols, it.period = part.data_ptr(), res.data_ptr() + off * 4, part.shape[0], part.shape[1], period
+    check(_lib.load().advhip_colsum_group_f32(arr, len(items), stream(dev)), "colsum_group")
+    return [res[off : off + part.shape[1]] for (part, _p), off in zip(items, offs)]
+
+
 def chan_stats(x: torch.Tensor, eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
     """(mean, 1 / (std_biased + eps)) over the channels of a contiguous (C, B, T) activation, per position."""
     _lib.require_gpu(x)
@@ -354,7 +373,7 @@ class _Fork:
 # AccumulateGrad would have (param.grad = g, or += g).  Same kernels, slices and summation order as the per-layer launches: the
 # same bits.  Opt-in because only `.backward()` sees these gradients -- `torch.autograd.grad` and parameter hooks do not; the
 # trainer's step (train_graph.GraphedTrainStep, runner.Trainer) turns it on.
-_DEFER = {"on": False, "items": [], "queued": False}
+_DEFER = {"on": False, "items": [], "colsums": [], "queued": False}
 DEFER_DW = os.environ.get("ADV_MGFN_DEFER_DW", "1") == "1"  # what the trainer's step passes to deferred_param_grads
 
 
@@ -369,14 +388,35 @@ class deferred_param_grads:
 
     def __exit__(self, *exc):
         _DEFER["on"] = self.prev
-        if _DEFER["items"]:  # (a backward pass that never finished: drop what it left)
+        if _DEFER["items"] or _DEFER["colsums"]:  # (a backward pass that never finished: drop what it left)
             _DEFER["items"].clear()
+            _DEFER["colsums"].clear()
             _DEFER["queued"] = False
         return False
 
 
+def _accumulate(p, g) -> None:
+    """What autograd's AccumulateGrad does with a leaf's gradient."""
+    if p.grad is None:
+        p.grad = g
+    else:
+        p.grad.add_(g)
+
+
 def _flush_deferred() -> None:
-    items, _DEFER["items"], _DEFER["queued"] = _DEFER["items"], [], False
+    items, _DEFER["items"] = _DEFER["items"], []
+    colsums, _DEFER["colsums"] = _DEFER["colsums"], []
+    _DEFER["queued"] = False
+    with torch.no_grad():
+        by_dev = {}
+        for it in colsums:
+            by_dev.setdefault(it[0].device, []).append(it)
+        for dev, group in by_dev.items():
+            with torch.cuda.device(dev):
+                sums = colsum_group([(part, period) for part, period, _t in group])
+            for (_part, _period, targets), s in zip(group, sums):
+                for p, lo, hi in targets:
+                    _accumulate(p, s[lo:hi].view(p.shape))
     if not items:
         return
     by_k = {}
@@ -387,13 +427,25 @@ def _flush_deferred() -> None:
             with torch.cuda.device(group[0][0].device):
                 outs = ops.gemm_nt_group([(g2, x2, bp is not None) for g2, x2, _wp, bp in group])
             for (g2, x2, wp, bp), (dw, db) in zip(group, outs):
-                for p, g in ((wp, dw.view(wp.shape)), (bp, db)):
-                    if p is None:
-                        continue
-                    if p.grad is None:
-                        p.grad = g
-                    else:
-                        p.grad.add_(g)
+                _accumulate(wp, dw.view(wp.shape))
+                if bp is not None:
+                    _accumulate(bp, db)
+
+
+def _queue_flush() -> None:
+    if not _DEFER["queued"]:
+        _DEFER["queued"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
+
+
+def _defer_colsum(partial: torch.Tensor, targets, period: int = 0) -> bool:
+    """Queue the column sums of a (rows, cols) partial-sum matrix; `targets` = [(parameter, lo, hi), ...]: columns [lo, hi) of the
+    (de-interleaved, see advhip_colsum_group_f32) sums are that parameter's gradient.  False = the caller sums now."""
+    if not (_DEFER["on"] and targets and all(p is not None for p, _lo, _hi in targets)):
+        return False
+    _DEFER["colsums"].append((partial, period, targets))
+    _queue_flush()
+    return True
 
 
 def _defer_dw(g2: torch.Tensor, x2: torch.Tensor, wparam, bparam) -> bool:
@@ -402,9 +454,7 @@ def _defer_dw(g2: torch.Tensor, x2: torch.Tensor, wparam, bparam) -> bool:
             and g2.is_contiguous() and x2.is_contiguous()):
         return False
     _DEFER["items"].append((g2, x2, wparam, bparam))
-    if not _DEFER["queued"]:
-        _DEFER["queued"] = True
-        torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
+    _queue_flush()
     return True
 
 
@@ -544,6 +594,7 @@ class _FFNBlockCN(torch.autograd.Function):
         y = conv_cn(h, pack_kc_cached(w2, fresh), c, 1, shift=b2.detach(), residual=x)
         ctx.save_for_backward(x, gf, mu, rs, xh, z, h, w1, w2)
         ctx.params = (w1, b1, w2, b2)
+        ctx.ln_params = (g, b)
         ctx.eps, ctx.gshape = eps, g.shape
         return y
 
@@ -565,6 +616,9 @@ class _FFNBlockCN(torch.autograd.Function):
         pgb = torch.empty((rows, 2 * dim), device=x.device, dtype=torch.float32)
         check(lib.advhip_chan_layernorm_bwd_add_f32(ptr(dxh), ptr(x), ptr(gf), ptr(mu), ptr(rs), ptr(dy), ptr(dx), ptr(pgb), dim, n,
                                                     C.c_float(ctx.eps), stream(x)), "chan_layernorm_bwd_add")
+        gp, bp = ctx.ln_params
+        if need[1] and need[2] and _defer_colsum(pgb, [(gp, 0, dim), (bp, dim, 2 * dim)]):
+            return dx, None, None, None, dw1, db1, dw2, db2, None
         sums = colsum(pgb)
         return dx, sums[:dim].reshape(ctx.gshape), sums[dim:].reshape(ctx.gshape), None, dw1, db1, dw2, db2, None
 
@@ -610,6 +664,7 @@ class _FocusAttnBlockCN(torch.autograd.Function):
         y = conv_cn(o, pack_kc_cached(wo, fresh), c, 1, shift=bo.detach(), residual=x)
         ctx.save_for_backward(x, bn_w, mean, var, xb, v, w2, o, wv, wo)
         ctx.params = (wv, wo, bo)
+        ctx.rel_params = (wrel, brel)
         ctx.eps, ctx.heads, ctx.wrel_shape = bn.eps, heads, wrel.shape
         return y
 
@@ -629,7 +684,13 @@ class _FocusAttnBlockCN(torch.autograd.Function):
         dv = torch.empty_like(v)
         partial = torch.empty((inner * chunks, k + 1), device=x.device, dtype=torch.float32)
         check(lib.advhip_dwconv_t_bwd_f32(ptr(do), ptr(v), ptr(w2), ptr(dv), ptr(partial), inner, heads, b_, t, k, stream(x)), "dwconv_t_bwd")
-        per_head = colsum(partial.view(inner // heads * chunks, heads * (k + 1))).view(heads, k + 1)  # rows = (c_idx, chunk)
+        wrelp, brelp = ctx.rel_params
+        p2 = partial.view(inner // heads * chunks, heads * (k + 1))  # rows = (c_idx, chunk)
+        if need[4] and need[5] and _defer_colsum(p2, [(wrelp, 0, heads * k), (brelp, heads * k, heads * (k + 1))], period=k + 1):
+            dwrel = dbrel = None
+        else:
+            per_head = colsum(p2).view(heads, k + 1)
+            dwrel, dbrel = per_head[:, :k].reshape(ctx.wrel_shape), per_head[:, k].contiguous()
         dwv, _ = _dw_db(dv, xb, need[3], False, wvp, None)
         dxb = conv_cn(dv, wv.detach().view(inner, c), c, 1)
         dx = torch.empty_like(x)
@@ -637,7 +698,7 @@ class _FocusAttnBlockCN(torch.autograd.Function):
         db = torch.empty_like(dg)
         check(lib.advhip_bn_rows_bwd_add_f32(ptr(dxb), ptr(x), ptr(bn_w.detach()), ptr(mean), ptr(var), ptr(dy), ptr(dx), ptr(dg), ptr(db), c,
                                              b_ * t, C.c_float(ctx.eps), stream(x)), "bn_rows_bwd_add")
-        return dx, dg, db, dwv, per_head[:, :k].reshape(ctx.wrel_shape), per_head[:, k].contiguous(), dwo, dbo, None, None, None
+        return dx, dg, db, dwv, dwrel, dbrel, dwo, dbo, None, None, None
 
 
 class _GlanceAttnCore(torch.autograd.Function):
@@ -694,6 +755,7 @@ class _HeadLnFc(torch.autograd.Function):
         check(_lib.load().advhip_head_ln_fc_fwd_f32(ptr(y), ptr(ln_w.detach()), ptr(ln_b.detach()), ptr(fc_w.detach()), ptr(fc_b.detach()), ptr(xn), ptr(mean),
                                                     ptr(rstd), ptr(score), c, n, C.c_float(eps), stream(y)), "head_ln_fc_fwd")
         ctx.save_for_backward(y, ln_w, ln_b, fc_w, mean, rstd, score)
+        ctx.head_params = (ln_w, ln_b, fc_w, fc_b)
         return xn, score
 
     @staticmethod
@@ -709,6 +771,9 @@ class _HeadLnFc(torch.autograd.Function):
         d_score = None if d_score is None else d_score.contiguous()
         check(lib.advhip_head_ln_fc_bwd_f32(ptr(d_xn), ptr(d_score), ptr(y), ptr(ln_w.detach()), ptr(ln_b.detach()), ptr(fc_w.detach()), ptr(mean), ptr(rstd),
                                             ptr(score), ptr(dy), ptr(partial), c, n, stream(y)), "head_ln_fc_bwd")
+        lw, lb, fw, fb = ctx.head_params
+        if all(ctx.needs_input_grad[i] for i in (1, 2, 4, 5)) and _defer_colsum(partial, [(lw, 0, c), (lb, c, 2 * c), (fw, 2 * c, 3 * c), (fb, 3 * c, 3 * c + 1)]):
+            return dy, None, None, None, None, None
         sums = colsum(partial)
         return dy, sums[:c], sums[c : 2 * c], None, sums[2 * c : 3 * c].view(1, c), sums[3 * c :]
 
@@ -797,6 +862,7 @@ class _ChanLayerNorm(torch.autograd.Function):
               "chan_layernorm_fwd")
         ctx.save_for_backward(x, gf, mu, rs)
         ctx.eps, ctx.gshape = eps, g.shape
+        ctx.ln_params = (g, b)
         return y
 
     @staticmethod
@@ -812,6 +878,9 @@ class _ChanLayerNorm(torch.autograd.Function):
         pb = torch.empty_like(pg)
         check(lib.advhip_chan_layernorm_bwd_f32(ptr(dy), ptr(x), ptr(gf), ptr(mu), ptr(rs), ptr(dx), ptr(pg), ptr(pb), c, n,
                                                 C.c_float(ctx.eps), stream(x)), "chan_layernorm_bwd")
+        gp, bp = ctx.ln_params
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and _defer_colsum(pg, [(gp, 0, c)]) and _defer_colsum(pb, [(bp, 0, c)]):
+            return dx, None, None, None
         return dx, colsum(pg).view(ctx.gshape), colsum(pb).view(ctx.gshape), None
 
 

@@ -411,6 +411,19 @@ int advhip_pack_weights_multi_f32(const advhip_pack_item* items_dev, int32_t n_i
 /* dst[c] = sum over r, in row order, of src[r][c]: the per-block partial sums the backward kernels above leave to the caller
  * (rows = a few hundred blocks). */
 int advhip_colsum_f32(const float* src, float* dst, int64_t rows, int32_t cols, void* stream);
+/* The same for many matrices in one launch (`items`: a HOST array, 64 per launch, carried in the kernel arguments): all partial-sum
+ * matrices of a backward pass at its end.  period > 0: the columns are [cols / period groups][period] and leave de-interleaved --
+ * element j < period - 1 of group h at dst[h * (period - 1) + j], the last element of every group at
+ * dst[(cols / period) * (period - 1) + h]: advhip_dwconv_t_bwd_f32's per-head (K filter taps | bias) sums as the filter gradient
+ * followed by the bias gradient (period = K + 1). */
+typedef struct advhip_colsum_item {
+  const float* src;
+  float* dst;
+  int64_t rows;
+  int32_t cols;
+  int32_t period;
+} advhip_colsum_item;
+int advhip_colsum_group_f32(const advhip_colsum_item* items, int32_t n_items, void* stream);
 
 /* The operand of a k = 3, padding 1 Conv1d's weight gradient (autograd of nn.Conv1d, modeling_mgfn.py:101,155):
  * u[(c*3 + j), r, t] = x[c, r, t + j - 1] (zero outside [0, T)), x (C, rows, T) -> u (3C, rows, T); dW = dY . u^T by

@@ -490,3 +490,23 @@ def test_gemm_nt_group_equals_the_single_launches():
         assert rel_err(c.cpu().double(), a.cpu().double() @ b.cpu().double().t()) < 1e-5
     with pytest.raises(ValueError):
         ops.gemm_nt_group([(items[0][0], items[1][1][:, :1280], False)])
+
+
+def test_colsum_group_equals_the_single_launches():
+    """advhip_colsum_group_f32: 70 partial-sum matrices (more than one kernel-argument block of 64) in one launch, bit for bit
+    advhip_colsum_f32 of each; `period`: the depth-wise conv's (taps | bias) per-head sums leave as filter gradient, then bias."""
+    from anomaly_detection_on_video_amd import mgfn_ops
+
+    items = []
+    for i in range(70):
+        rows, cols, period = [(160, 2048, 0), (37, 128, 0), (320, 48, 6), (5, 3073, 0), (64, 8, 4), (200, 1, 0), (9, 96, 6)][i % 7]
+        items.append((synth_tensor(f"csg.{i}", (rows, cols)).to(DEV), period))
+    outs = mgfn_ops.colsum_group(items)
+    for (part, period), got in zip(items, outs):
+        want = mgfn_ops.colsum(part)
+        if period:
+            h = part.shape[1] // period
+            want = torch.cat([want.view(h, period)[:, : period - 1].reshape(-1), want.view(h, period)[:, period - 1]])
+        assert torch.equal(got, want)
+        assert rel_err(want.cpu().double(), (torch.cat([part.sum(0).view(-1, period)[:, : period - 1].reshape(-1), part.sum(0).view(-1, period)[:, period - 1]])
+                                             if period else part.sum(0)).cpu().double()) < 1e-5
