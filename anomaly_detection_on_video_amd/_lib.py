@@ -146,6 +146,8 @@ SIGNATURES = {
     "advhip_bn_rows_bwd_add_f32": (C.c_int, [_P] * 9 + [_I, _L, C.c_float, _P]),
     "advhip_chan_layernorm_bwd_add_f32": (C.c_int, [_P] * 8 + [_I, _L, C.c_float, _P]),
     "advhip_conv1d_pack_weight_dx_f32": (C.c_int, [_P, _P, _I, _I, _I, _P]),
+    "advhip_amp_combine_fwd_f32": (C.c_int, [_P, _P, _P, _L, _P, _P, C.c_float, _P, _I, _L, _I, _P]),
+    "advhip_amp_combine_bwd_f32": (C.c_int, [_P, _P, _L, C.c_float, _P, _P, _P, _P, _I, _L, _I, _P]),
     "advhip_colsum_f32": (C.c_int, [_P, _P, _L, _I, _P]),
     "advhip_colsum_group_f32": (C.c_int, [C.POINTER(ColsumItem), _I, _P]),
     "advhip_pack_item_tiles": (C.c_int64, [_I, _I, _I, _I]),

@@ -700,6 +700,72 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const advhip_pack_item*
     }
   }
 }
+
+// ---- MGFNFeatureAmplifier's combine step (modeling_mgfn.py:81-93) ------------------------------------------------------------
+// tokens = Conv1d_k3(features) + mag_ratio * Conv1d_k3(magnitude).  The 2048 -> 64 conv arrives as its three per-tap products
+// z[j] = W_j X (one GEMM on the input as stored); this launch finishes it -- the shifted add over the taps (zero outside [0, T)),
+// the bias -- and adds the whole 1 -> 64 magnitude conv, which is three multiply-adds per output.  torch: pad, slices, adds,
+// a second unfold + GEMM + bias for the magnitude, scale, add: ~20 launches forward, ~20 backward.
+__global__ __launch_bounds__(256) void amp_combine_fwd_kernel(const float* __restrict__ z, const float* __restrict__ bias, const float* __restrict__ mag,
+                                                              long long mag_stride, const float* __restrict__ wm, const float* __restrict__ bm,
+                                                              float ratio, float* __restrict__ y, int O, long long rows, int T) {
+  const long long n = rows * T, total = (long long)O * n;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int o = (int)(i / n);
+    const long long p = i - (long long)o * n;
+    const int t = (int)(p % T);
+    float acc = bias[o] + z[((long long)O + o) * n + p];                  // tap 1: the position itself
+    float m = wm[o * 3 + 1] * mag[p * mag_stride];
+    if (t > 0) {
+      acc += z[(long long)o * n + p - 1];                                  // tap 0 reads t - 1
+      m += wm[o * 3] * mag[(p - 1) * mag_stride];
+    }
+    if (t + 1 < T) {
+      acc += z[((long long)2 * O + o) * n + p + 1];                        // tap 2 reads t + 1
+      m += wm[o * 3 + 2] * mag[(p + 1) * mag_stride];
+    }
+    y[i] = acc + ratio * (m + bm[o]);
+  }
+}
+
+// backward: dz[j][o][p] = dy[o][p - j + 1] inside the row, else 0; one block per output channel o also reduces, in a fixed order,
+// d_bias[o] = sum dy, d_bm[o] = ratio * sum dy, d_wm[o][j] = ratio * sum dy[o][p] * mag[p + j - 1]
+__global__ __launch_bounds__(256) void amp_combine_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ mag, long long mag_stride,
+                                                              float ratio, float* __restrict__ dz, float* __restrict__ d_bias,
+                                                              float* __restrict__ d_wm, float* __restrict__ d_bm, int O, long long rows, int T) {
+  __shared__ float red[4][256];
+  const int o = blockIdx.x;
+  const long long n = rows * T;
+  const float* g = dy + (long long)o * n;
+  float s = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (long long p = threadIdx.x; p < n; p += 256) {
+    const int t = (int)(p % T);
+    const float v = g[p];
+    dz[((long long)O + o) * n + p] = v;
+    dz[(long long)o * n + p] = t + 1 < T ? g[p + 1] : 0.f;                 // z[0][p] fed output p + 1
+    dz[((long long)2 * O + o) * n + p] = t > 0 ? g[p - 1] : 0.f;           // z[2][p] fed output p - 1
+    s += v;
+    s1 += v * mag[p * mag_stride];
+    if (t > 0) s0 += v * mag[(p - 1) * mag_stride];
+    if (t + 1 < T) s2 += v * mag[(p + 1) * mag_stride];
+  }
+  red[0][threadIdx.x] = s; red[1][threadIdx.x] = s0; red[2][threadIdx.x] = s1; red[3][threadIdx.x] = s2;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    d_bias[o] = red[0][0];
+    d_bm[o] = ratio * red[0][0];
+    d_wm[o * 3] = ratio * red[1][0];
+    d_wm[o * 3 + 1] = ratio * red[2][0];
+    d_wm[o * 3 + 2] = ratio * red[3][0];
+  }
+}
 }  // namespace advhip
 
 using namespace advhip;
@@ -900,4 +966,21 @@ extern "C" int advhip_colsum_group_f32(const advhip_colsum_item* items, int32_t 
     if (int rc = check_launch("colsum_group")) return rc;
   }
   return ADVHIP_OK;
+}
+
+extern "C" int advhip_amp_combine_fwd_f32(const float* z, const float* bias, const float* mag, int64_t mag_stride, const float* wm, const float* bm,
+                                          float ratio, float* y, int32_t O, int64_t rows, int32_t T, void* stream) {
+  ADVHIP_REQUIRE(z && bias && mag && wm && bm && y && O > 0 && rows > 0 && T > 0 && mag_stride > 0, "amp_combine_fwd: bad arguments");
+  const long long total = (long long)O * rows * T;
+  hipLaunchKernelGGL(amp_combine_fwd_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, z, bias, mag,
+                     (long long)mag_stride, wm, bm, ratio, y, O, (long long)rows, T);
+  return check_launch("amp_combine_fwd");
+}
+
+extern "C" int advhip_amp_combine_bwd_f32(const float* dy, const float* mag, int64_t mag_stride, float ratio, float* dz, float* d_bias, float* d_wm,
+                                          float* d_bm, int32_t O, int64_t rows, int32_t T, void* stream) {
+  ADVHIP_REQUIRE(dy && mag && dz && d_bias && d_wm && d_bm && O > 0 && rows > 0 && T > 0 && mag_stride > 0, "amp_combine_bwd: bad arguments");
+  hipLaunchKernelGGL(amp_combine_bwd_kernel, dim3((unsigned)O), dim3(256), 0, (hipStream_t)stream, dy, mag, (long long)mag_stride, ratio, dz, d_bias, d_wm,
+                     d_bm, O, (long long)rows, T);
+  return check_launch("amp_combine_bwd");
 }

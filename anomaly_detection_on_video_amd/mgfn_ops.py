@@ -914,6 +914,46 @@ class _DWConvT(torch.autograd.Function):
         return dv, per_head[:, :k].reshape(ctx.wshape), per_head[:, k].contiguous()
 
 
+class _AmpCombine(torch.autograd.Function):
+    """tokens = sum_j shift_j(z[j]) + bias + ratio * Conv1d_k3(magnitude): what follows the tap GEMM in MGFNFeatureAmplifier
+    (modeling_mgfn.py:81-93) as one launch forward and one backward (include/advhip.h: advhip_amp_combine_*_f32)."""
+
+    @staticmethod
+    def forward(ctx, z, bias, mag, wm, bm, ratio):
+        _lib.require_gpu(z, bias, wm, bm)
+        _lib.require_gpu(mag, contiguous=False)
+        k, o, b, t = z.shape
+        y = torch.empty((o, b, t), device=z.device, dtype=torch.float32)
+        check(_lib.load().advhip_amp_combine_fwd_f32(ptr(z), ptr(bias.detach()), ptr(mag), mag.stride(2), ptr(wm.detach()), ptr(bm.detach()),
+                                                     C.c_float(ratio), ptr(y), o, b, t, stream(z)), "amp_combine_fwd")
+        ctx.mag, ctx.ratio = mag, ratio
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        o, b, t = dy.shape
+        mag = ctx.mag
+        dz = torch.empty((3, o, b, t), device=dy.device, dtype=torch.float32)
+        d_bias = torch.empty((o,), device=dy.device, dtype=torch.float32)
+        d_bm = torch.empty_like(d_bias)
+        d_wm = torch.empty((o, 1, 3), device=dy.device, dtype=torch.float32)
+        check(_lib.load().advhip_amp_combine_bwd_f32(ptr(dy), ptr(mag), mag.stride(2), C.c_float(ctx.ratio), ptr(dz), ptr(d_bias), ptr(d_wm), ptr(d_bm),
+                                                     o, b, t, stream(dy)), "amp_combine_bwd")
+        return dz, d_bias, None, d_wm, d_bm, None
+
+
+def amp_combine_ok(z: torch.Tensor, conv: torch.nn.Conv1d, to_mag: torch.nn.Conv1d, mag: torch.Tensor) -> bool:
+    """`mag`: the (1, B, T) magnitude channel as a view of the input (b, t) rows -- element (b, t) at (b * T + t) * stride(2)."""
+    return (z.dim() == 4 and z.shape[0] == 3 and _on_current_device(z) and z.dtype == torch.float32 and z.is_contiguous() and conv.bias is not None
+            and to_mag.bias is not None and tuple(to_mag.weight.shape) == (z.shape[1], 1, 3) and mag.dim() == 3 and mag.shape[0] == 1
+            and mag.stride(1) == mag.shape[2] * mag.stride(2) and not mag.requires_grad and mag.dtype == torch.float32 and _on_current_device(mag))
+
+
+def amp_combine(z, conv, to_mag, mag, ratio: float) -> torch.Tensor:
+    return _AmpCombine.apply(z, conv.bias, mag, to_mag.weight, to_mag.bias, float(ratio))
+
+
 def fused_ok(x: torch.Tensor) -> bool:
     return _on_current_device(x) and x.dtype == torch.float32 and x.dim() == 3
 

@@ -172,7 +172,9 @@ class MGFNFeatureAmplifier(nn.Module):
         bs, ncrops, t, c = x.shape
         x = x.reshape(bs * ncrops, t, c).permute(2, 0, 1)  # (C+1, B, T) view
         if torch.is_grad_enabled() and self.to_tokens.weight.requires_grad:
-            tokens = self._tokens_by_taps(x, bs * ncrops, t)
+            tokens, whole = self._tokens_by_taps(x, bs * ncrops, t)
+            if whole:  # (the magnitude conv, the scale and the sum went into the launch that finishes the token conv)
+                return tokens
         else:
             tokens = _conv_k(self.to_tokens, x[: self.channels])
         return tokens + self.mag_ratio * _conv_k(self.to_mag, x[self.channels :])
@@ -187,11 +189,15 @@ class MGFNFeatureAmplifier(nn.Module):
         o, c, k = conv.weight.shape
         xv = x[:c].reshape(c, b * t)                                      # (C, B*T) view of the (B*T, C+1) rows: strides (1, C+1)
         z = torch.matmul(conv.weight.permute(2, 0, 1).reshape(k * o, c), xv).view(k, o, b, t)
+        mag = x[c:]
+        if k == 3 and mgfn_ops.amp_combine_ok(z, conv, self.to_mag, mag):
+            # the shifted add, the bias AND mag_ratio * to_mag(magnitude): one HIP launch forward, one backward -> (tokens, True)
+            return mgfn_ops.amp_combine(z, conv, self.to_mag, mag, self.mag_ratio), True
         zp = F.pad(z, (k // 2, k // 2))
         y = zp[0, :, :, 0:t]
         for j in range(1, k):
             y = y + zp[j, :, :, j : j + t]
-        return y + conv.bias.view(-1, 1, 1) if conv.bias is not None else y
+        return (y + conv.bias.view(-1, 1, 1) if conv.bias is not None else y), False
 
 
 class GlanceAttention(nn.Module):

@@ -408,6 +408,15 @@ typedef struct advhip_pack_item {
 int64_t advhip_pack_item_tiles(int32_t Cout, int32_t Cin, int32_t k, int32_t mode);
 int advhip_pack_weights_multi_f32(const advhip_pack_item* items_dev, int32_t n_items, int32_t n_tiles, void* stream);
 
+/* MGFNFeatureAmplifier (modeling_mgfn.py:81-93) after the GEMM of the stacked tap matrices: y[o, r, t] = sum_j z[j, o, r, t + j - 1]
+ * (zero outside [0, T)) + bias[o] + ratio * (sum_j wm[o][j] * mag[r, t + j - 1] + bm[o]) for z (3, O, rows, T), mag = the magnitude
+ * channel read in place: element (r, t) at mag[(r * T + t) * mag_stride].  Backward: dz (3, O, rows, T), d_bias (O), d_wm (O, 3),
+ * d_bm (O) -- the magnitude itself gets no gradient (it is input data). */
+int advhip_amp_combine_fwd_f32(const float* z, const float* bias, const float* mag, int64_t mag_stride, const float* wm, const float* bm,
+                               float ratio, float* y, int32_t O, int64_t rows, int32_t T, void* stream);
+int advhip_amp_combine_bwd_f32(const float* dy, const float* mag, int64_t mag_stride, float ratio, float* dz, float* d_bias, float* d_wm,
+                               float* d_bm, int32_t O, int64_t rows, int32_t T, void* stream);
+
 /* dst[c] = sum over r, in row order, of src[r][c]: the per-block partial sums the backward kernels above leave to the caller
  * (rows = a few hundred blocks). */
 int advhip_colsum_f32(const float* src, float* dst, int64_t rows, int32_t cols, void* stream);

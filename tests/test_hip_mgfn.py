@@ -510,3 +510,36 @@ def test_colsum_group_equals_the_single_launches():
         assert torch.equal(got, want)
         assert rel_err(want.cpu().double(), (torch.cat([part.sum(0).view(-1, period)[:, : period - 1].reshape(-1), part.sum(0).view(-1, period)[:, period - 1]])
                                              if period else part.sum(0)).cpu().double()) < 1e-5
+
+
+def test_amp_combine_matches_torch_forward_and_backward():
+    """advhip_amp_combine_*_f32: the shifted add over the tap products + bias + mag_ratio * Conv1d_k3(magnitude)
+    (/root/reference/src/models/mgfn/modeling_mgfn.py:81-93) vs torch's pad / slice / conv1d autograd in fp64; the magnitude
+    is read in place through the (B, T, C + 1) input's strides."""
+    import torch.nn.functional as F
+
+    from anomaly_detection_on_video_amd import mgfn_ops
+
+    o, b, t, c1 = 64, 12, 32, 9
+    x = synth_tensor("amp.x", (b, t, c1)).to(DEV)
+    mag = x.permute(2, 0, 1)[c1 - 1 :]                       # (1, B, T) view, stride(2) = c1
+    z = synth_tensor("amp.z", (3, o, b, t)).to(DEV).requires_grad_(True)
+    conv = torch.nn.Conv1d(5, o, 3, padding=1).to(DEV)
+    to_mag = torch.nn.Conv1d(1, o, 3, padding=1).to(DEV)
+    with torch.no_grad():
+        conv.bias.copy_(synth_tensor("amp.b", (o,)).to(DEV))
+        to_mag.weight.copy_(synth_tensor("amp.wm", (o, 1, 3)).to(DEV))
+        to_mag.bias.copy_(synth_tensor("amp.bm", (o,)).to(DEV))
+    assert mgfn_ops.amp_combine_ok(z, conv, to_mag, mag)
+    y = mgfn_ops.amp_combine(z, conv, to_mag, mag, 0.1)
+    gy = synth_tensor("amp.gy", (o, b, t)).to(DEV)
+    y.backward(gy)
+    got = [y.detach(), z.grad, conv.bias.grad, to_mag.weight.grad, to_mag.bias.grad]
+    zd = z.detach().double().requires_grad_(True)
+    bias, wm, bm = (p.detach().double().requires_grad_(True) for p in (conv.bias, to_mag.weight, to_mag.bias))
+    zp = F.pad(zd, (1, 1))
+    yr = zp[0, :, :, 0:t] + zp[1, :, :, 1 : t + 1] + zp[2, :, :, 2 : t + 2] + bias.view(-1, 1, 1)
+    yr = yr + 0.1 * F.conv1d(mag.double().permute(1, 0, 2), wm, bm, padding=1).permute(1, 0, 2)
+    yr.backward(gy.double())
+    for g, w in zip(got, [yr.detach(), zd.grad, bias.grad, wm.grad, bm.grad]):
+        assert g.shape == w.shape and rel_err(g.cpu().double(), w.cpu()) < 1e-6
