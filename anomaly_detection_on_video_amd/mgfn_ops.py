@@ -744,6 +744,7 @@ class _HeadLnFc(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, ln_w, ln_b, eps, fc_w, fc_b):
+        ctx.set_materialize_grads(False)  # (an unused output's gradient arrives as None, not as a zero-filled tensor)
         _lib.require_gpu(y, ln_w, ln_b, fc_w, fc_b)
         c, b, t = y.shape
         n = b * t

@@ -22,6 +22,7 @@ from ._lib import check, ptr, require_gpu, stream
 class _MilMagnitude(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features: torch.Tensor, scores: torch.Tensor, bs: int, ncrops: int):
+        ctx.set_materialize_grads(False)  # (unused output gradients arrive as None, not as zero-filled tensors)
         features = features.contiguous()
         scores = scores.contiguous()
         require_gpu(features, scores)
@@ -52,6 +53,7 @@ class _MilMagnitude(torch.autograd.Function):
 class _MilTopkSelect(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mag, keep, sc, features, ncrops: int, k: int):
+        ctx.set_materialize_grads(False)  # (unused output gradients arrive as None, not as zero-filled tensors)
         mag, sc, features = mag.contiguous(), sc.contiguous(), features.contiguous()
         keep = None if keep is None else keep.contiguous()
         require_gpu(mag, keep, sc, features)
@@ -97,6 +99,7 @@ class _MilTopkSelectSplit(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mag, keep_a, keep_n, sc, features, ncrops: int, k: int):
+        ctx.set_materialize_grads(False)  # (unused output gradients arrive as None, not as zero-filled tensors)
         mag, sc, features = mag.contiguous(), sc.contiguous(), features.contiguous()
         require_gpu(mag, keep_a, keep_n, sc, features)
         bs, T = mag.shape
@@ -151,6 +154,7 @@ def mil_topk_select_split(mag, keep_a: Optional[torch.Tensor], keep_n: Optional[
 class _MgfnLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sc, abn_score, nor_score, a_feat, n_feat, abn_labels, nor_labels, ncrops: int):
+        ctx.set_materialize_grads(False)  # (unused output gradients arrive as None, not as zero-filled tensors)
         args = [t.contiguous().float() for t in (sc, abn_score, nor_score, a_feat, n_feat, abn_labels, nor_labels)]
         require_gpu(*args)
         sc, abn_score, nor_score, a_feat, n_feat, abn_labels, nor_labels = args
