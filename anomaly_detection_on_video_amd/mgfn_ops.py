@@ -143,6 +143,10 @@ _STEP_PACKS: Dict[int, Tuple] = {}
 _PACK_PLANS: Dict[Tuple, Tuple] = {}
 
 
+# advhip_pack_item (include/advhip.h), as a numpy record: the item table lives in device memory
+PACK_ITEM_FIELDS = [("src", "<u8"), ("dst", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"), ("k", "<i4"), ("mode", "<i4"), ("tile_begin", "<i4"), ("reserved", "<i4")]
+
+
 def step_packs(convs) -> None:
     """Pack, in ONE launch (advhip_pack_weights_multi_f32), the forward GEMM operand of every Conv1d in `convs` and the
     transposed-conv operand of the k > 1 ones; until end_step_packs() the autograd Functions below take these instead of
@@ -157,8 +161,7 @@ def step_packs(convs) -> None:
     plan = _PACK_PLANS.get(key)
     if plan is None:
         lib = _lib.load()
-        item_t = np.dtype([("src", "<u8"), ("dst", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"), ("k", "<i4"), ("mode", "<i4"),
-                           ("tile_begin", "<i4"), ("reserved", "<i4")])
+        item_t = np.dtype(PACK_ITEM_FIELDS)
         rows, bufs, tiles = [], {}, 0
         for w in ws:
             _lib.require_gpu(w)

@@ -303,3 +303,53 @@ def test_checkpoint_carries_the_keys_lightning_reads():
     assert isinstance(st["pytorch-lightning_version"], str) and st["pytorch-lightning_version"].split(".")[0] == "2"
     assert set(st["state_dict"]) == {"model.weight", "model.bias"} and st["epoch"] == 3 and st["global_step"] == 17
     assert isinstance(st["callbacks"], dict) and isinstance(st["loops"], dict) and len(st["optimizer_states"]) == 1
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """Every struct that crosses the C ABI: size and field offsets of the ctypes mirror (_lib.py) equal what a C compiler makes of
+    include/advhip.h -- a field added on one side only would otherwise shift every later operand silently."""
+    import ctypes as C
+    import shutil
+    import subprocess
+
+    from anomaly_detection_on_video_amd import _lib
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pairs = {"advhip_conv3d_desc": _lib.ConvDesc, "advhip_conv3d_epilogue": _lib.ConvEpilogue, "advhip_gemm_desc": _lib.GemmDesc,
+             "advhip_nt_item": _lib.NtItem, "advhip_colsum_item": _lib.ColsumItem}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "advhip.h"', "int main(void) {"]
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _t in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    got = {}
+    for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines():
+        cname, what, val = ln.split()
+        got[(cname, what)] = int(val)
+    for cname, cls in pairs.items():
+        assert got[(cname, "size")] == C.sizeof(cls), cname
+        for fname, _t in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+    assert C.sizeof(C.c_void_p) == 8
+    # the multi-pack item table is built as a numpy record array (mgfn_ops.step_packs): the same check against its dtype
+    import numpy as np
+
+    from anomaly_detection_on_video_amd import mgfn_ops
+
+    dt = np.dtype(mgfn_ops.PACK_ITEM_FIELDS)
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "advhip.h"', "int main(void) {", '  printf("size %zu\\n", sizeof(advhip_pack_item));']
+    lines += [f'  printf("{n} %zu\\n", offsetof(advhip_pack_item, {n}));' for n in dt.names]
+    lines += ["  return 0;", "}"]
+    src.write_text("\n".join(lines))
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(ln.split() for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    assert int(out["size"]) == dt.itemsize
+    for n in dt.names:
+        assert int(out[n]) == dt.fields[n][1], n
