@@ -5,7 +5,13 @@ Dev-only: needs /root/reference (read-only), which exists in the build container
 the GPU box.  The outputs (*.npz, small) are committed; nothing at test/bench time reads the
 reference.  Run from anywhere:
 
-    python -B tests/golden/make_golden.py
+    python -B tests/golden/make_golden.py [--out DIR] [i3d nonlocal mgfn host preproc]
+
+With no target every fixture is regenerated; `--out DIR` writes them somewhere else than tests/golden/ (what
+tests/test_oracle_golden.py::test_committed_goldens_regenerate_from_the_reference does, to compare array for array
+with the committed files).  Whatever the order on the command line, the targets run in one fixed order: the ones that
+import `transformers` (through the reference's modeling_mgfn) first, the ones that register the torchvision / decord
+placeholders last.
 
 The reference imports three third-party packages that are absent from this image and are not
 used by the code under test (pytorchvideo: only the `i3d_8x8_r50` factory branch; decord /
@@ -26,6 +32,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = HERE  # where the .npz files go (--out)
 REPO = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 
@@ -51,8 +58,16 @@ _placeholder("pytorchvideo.models.resnet", create_resnet=None)
 
 
 def _video_io_placeholders():
-    # only for importing the reference's extract_features.py / src/dataset.py (golden_host);
-    # registered late because `transformers` probes torchvision's import spec
+    # only for importing the reference's extract_features.py / src/dataset.py / src/gtransforms.py (golden_host,
+    # golden_preproc).  `transformers` probes torchvision's import spec when its lazy modules load, and dies on a
+    # placeholder: so load what the reference's modeling_mgfn needs from it BEFORE the placeholder exists, and run the
+    # targets in TARGETS' order (placeholders last).
+    if "torchvision" in sys.modules:
+        return
+    try:
+        from transformers import PreTrainedModel, PretrainedConfig  # noqa: F401
+    except Exception:  # pragma: no cover - transformers absent: nothing probes torchvision then
+        pass
     _placeholder("decord")
     tv = _placeholder("torchvision")
     tv.transforms = _placeholder("torchvision.transforms")
@@ -124,7 +139,7 @@ def golden_i3d():
     x = synth_input((1, 3, 8, 112, 96), 7)
     with torch.no_grad():
         out["feat_small"] = model(x).reshape(1, 2048).numpy()
-    np.savez_compressed(os.path.join(HERE, "i3d_fullnet.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "i3d_fullnet.npz"), **out)
     print("i3d_fullnet.npz", {k: v.shape for k, v in out.items() if k.startswith("feat")})
 
     # (iii) block-level micro-goldens through the reference's own Bottleneck on reduced shapes
@@ -168,7 +183,7 @@ def golden_i3d():
             y = blk(x)
         micro[f"{name}_y"] = y.numpy()
         micro[f"{name}_cfg"] = np.array([inpl, planes, stride, tc, int(has_ds), b, t, h, w], dtype=np.int64)
-    np.savez_compressed(os.path.join(HERE, "i3d_blocks.npz"), **micro)
+    np.savez_compressed(os.path.join(OUT, "i3d_blocks.npz"), **micro)
     print("i3d_blocks.npz", {k: v.shape for k, v in micro.items() if k.endswith("_y")})
 
 
@@ -192,7 +207,7 @@ def golden_nonlocal():
     with torch.no_grad():
         out["feat_nl_small"] = model(synth_input((1, 3, 8, 112, 96), 7)).reshape(1, 2048).numpy()
         out["feat_nl_64"] = model(synth_input((2, 3, 16, 64, 64), 3)).reshape(2, 2048).numpy()
-    np.savez_compressed(os.path.join(HERE, "nonlocal.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "nonlocal.npz"), **out)
     print("nonlocal.npz", {k: v.shape for k, v in out.items()})
 
 
@@ -282,7 +297,7 @@ def golden_mgfn():
     # eval, no split, odd T (validation shape (1,10,T,2049))
     video57 = mgfn_inputs(1, 57, 3)
     run(video57, None, None, "eval57", training=False, force_split=False)
-    np.savez_compressed(os.path.join(HERE, "mgfn.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "mgfn.npz"), **out)
     print("mgfn.npz", {k: v.shape for k, v in out.items() if "scores" in k or "loss" in k})
 
     # stand-alone loss known-answers
@@ -294,7 +309,7 @@ def golden_mgfn():
     b = synth_tensor("loss.b", (30, 3), scale=100.0, offset=120.0)
     lo["con1"] = ContrastiveLoss()(a, b, 1).numpy()
     lo["con0"] = ContrastiveLoss()(a, b, 0).numpy()
-    np.savez_compressed(os.path.join(HERE, "loss.npz"), **lo)
+    np.savez_compressed(os.path.join(OUT, "loss.npz"), **lo)
     print("loss.npz", {k: float(v) for k, v in lo.items()})
 
 
@@ -319,7 +334,7 @@ def golden_host():
     item = ds[0]
     out["addmag"] = item["feature"]
     out["addmag_anomaly"] = item["anomaly"]
-    np.savez_compressed(os.path.join(HERE, "host.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "host.npz"), **out)
     print("host.npz", {k: v.shape for k, v in out.items()})
 
     # sklearn known-answer for the AUC restatement (runner.py:73-76)
@@ -330,7 +345,7 @@ def golden_host():
     fpr, tpr, _ = roc_curve(labels.tolist(), preds)
     prec, rec, _ = precision_recall_curve(labels.tolist(), preds)
     np.savez_compressed(
-        os.path.join(HERE, "auc.npz"), preds=preds, labels=labels,
+        os.path.join(OUT, "auc.npz"), preds=preds, labels=labels,
         roc_auc=np.array(auc(fpr, tpr)), pr_auc=np.array(auc(rec, prec)),
     )
     print("auc.npz", auc(fpr, tpr), auc(rec, prec))
@@ -361,19 +376,33 @@ def golden_preproc():
     x = (synth_tensor("preproc.std_in", (5, 10, 3, 8, 8), scale=0.5, offset=0.5) * 255).round().clamp(0, 255)
     out["std_in"] = x.numpy().copy()
     out["std_out"] = std(x.clone()).numpy()
-    np.savez_compressed(os.path.join(HERE, "preproc.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "preproc.npz"), **out)
     print("preproc.npz", {k: v.shape for k, v in out.items()})
 
 
+# fixed run order: everything that imports `transformers` before the torchvision / decord placeholders are registered
+TARGETS = (("i3d", golden_i3d), ("nonlocal", golden_nonlocal), ("mgfn", golden_mgfn), ("host", golden_host), ("preproc", golden_preproc))
+
+
+def main(argv=None) -> int:
+    import argparse
+
+    global OUT
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--out", default=HERE, help="directory the .npz fixtures are written to (default: tests/golden/)")
+    ap.add_argument("targets", nargs="*", help="any of: " + " ".join(n for n, _ in TARGETS) + " (default: all)")
+    ns = ap.parse_args(argv)
+    unknown = set(ns.targets) - {n for n, _ in TARGETS}
+    if unknown:
+        ap.error(f"unknown target(s) {sorted(unknown)}")
+    OUT = os.path.abspath(ns.out)
+    os.makedirs(OUT, exist_ok=True)
+    which = set(ns.targets) or {n for n, _ in TARGETS}
+    for name, fn in TARGETS:
+        if name in which:
+            fn()
+    return 0
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["i3d", "nonlocal", "mgfn", "host", "preproc"]
-    if "preproc" in which:
-        golden_preproc()
-    if "i3d" in which:
-        golden_i3d()
-    if "nonlocal" in which:
-        golden_nonlocal()
-    if "mgfn" in which:
-        golden_mgfn()
-    if "host" in which:
-        golden_host()
+    sys.exit(main())

@@ -267,3 +267,27 @@ def test_standardisation_order_vs_reference_golden():
     g = np.load(os.path.join(GOLDEN, "preproc.npz"))
     x = g["std_in"]
     assert np.array_equal((x - np.float32(114.75)) / np.float32(57.375), g["std_out"])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference tree is absent (GPU box): the committed fixtures stand alone")
+def test_committed_goldens_regenerate_from_the_reference(tmp_path):
+    """The oracle's pin checks itself: tests/golden/make_golden.py, run the documented way (no target arguments), imports
+    the reference and must reproduce every committed array bit for bit.  A drift of the generator, of the synthetic
+    inputs (weights.py) or of the import order its placeholders depend on fails here instead of going unnoticed."""
+    import subprocess
+    import sys
+
+    script = os.path.join(GOLDEN, "make_golden.py")
+    r = subprocess.run([sys.executable, "-B", script, "--out", str(tmp_path)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    committed = sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+    assert committed == sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz")), "the default invocation does not write every committed fixture"
+    arrays = 0
+    for f in committed:
+        a, b = np.load(os.path.join(GOLDEN, f)), np.load(os.path.join(tmp_path, f))
+        assert sorted(a.files) == sorted(b.files), f
+        for k in a.files:
+            assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape, (f, k)
+            assert np.array_equal(a[k], b[k]), f"{f}:{k} differs from the committed fixture"
+            arrays += 1
+    assert arrays >= 131
