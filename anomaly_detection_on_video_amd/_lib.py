@@ -205,9 +205,17 @@ def load(path: Optional[str] = None) -> C.CDLL:
     return lib
 
 
+ON_FAILURE: list = []  # callables run when an entry point reports an error (ops drops per-stream state a failed launch may have left dirty)
+
+
 def check(rc: int, what: str = "advhip") -> None:
     if rc != 0:
         msg = load().advhip_last_error().decode("utf-8", "replace")
+        for hook in ON_FAILURE:
+            try:
+                hook()
+            except Exception:  # pragma: no cover - a clean-up hook must not mask the error being reported
+                pass
         raise HipExtensionError(f"{what} failed (code {rc}): {msg}")
 
 

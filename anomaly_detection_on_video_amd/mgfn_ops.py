@@ -5,14 +5,19 @@ Y[o, n] = W[o, c] X[c, n] over n = (b, t), and that GEMM is a 1x1x1 convolution 
 (1, C, 1, 1, B*T) tensor (a k = 3 Conv1d: kernel (1,1,3) on (1, C, 1, B, T), im2col-free), with bias, GELU, residual, the
 channel-LayerNorm fold and the GELU backward in its epilogue (include/advhip.h: advhip_conv3d_bn_act_ex_f32).  Per layer:
 
-    forward   Y  = act(W X + b) (+ R)            conv kernel, weights re-packed to [c][o] when the parameter changed
+    forward   Y  = act(W X + b) (+ R)            conv kernel; every layer's [c][o] operand of a differentiated forward is packed
+                                                 by ONE launch (step_packs), inference re-uses cached packs
     backward  dX = W^T dY (* GELU'(z))           conv kernel on the parameter's own [o][c] layout (no packing)
-              dW = dY X^T                        advhip_gemm_nt_f32 (both operands position-contiguous: LDS-DMA row copies)
-              db = row sums of dY                torch reduction
+              dW = dY X^T, db = row sums of dY   ONE advhip_gemm_nt launch (both operands position-contiguous: LDS-DMA row
+                                                 copies; the n-tile-0 workgroups add up the dY fragments they hold anyway); the
+                                                 narrow layers' pairs all together in one grouped launch at the end of the
+                                                 backward pass (deferred_param_grads)
 
 Replaces the Conv1d calls of MGFNFeedForward / FocusAttention / FocusBlock / MGFNIntermediate
-(/root/reference/src/models/mgfn/modeling_mgfn.py:49-64, 150-216).  CUDA tensors only; layers that do not fit the
-kernels' shapes (fewer than 128 channels, Cout % 64 != 0, Cin % 32 != 0) stay on the torch ops of modeling_mgfn.py.
+(/root/reference/src/models/mgfn/modeling_mgfn.py:49-64, 150-216).  CUDA tensors on the current device only.  Shape rules
+(`eligible`): channel counts >= MIN_CHANNELS_* (64: every layer of the default architecture), Cout % 64 == 0, Cin % 32 == 0, and with
+autograd Cin % 64 == 0 and B*T % 16 == 0.  A layer outside these rules (a non-default architecture) takes the torch expression
+of the same arithmetic in modeling_mgfn.py -- DESIGN.md section 1 lists that branch; `ADV_MGFN_STRICT=1` makes it raise instead.
 """
 from __future__ import annotations
 
@@ -175,9 +180,15 @@ def step_packs(convs) -> None:
                 rows.append((w.data_ptr(), dst.data_ptr(), cout, cin, k, mode, tiles, 0))
                 tiles += int(lib.advhip_pack_item_tiles(cout, cin, k, mode))
         items = torch.from_numpy(np.array(rows, dtype=item_t).view(np.uint8).copy()).to(dev)
-        if len(_PACK_PLANS) >= 4:  # (parameters of discarded models)
-            _PACK_PLANS.clear()
+        # evict only plans of parameters that are gone (discarded models): a live plan's buffers may be baked into a captured
+        # HIP graph (train_graph.GraphedTrainStep also holds them itself, see hold_plans)
+        for k in [k for k, v in _PACK_PLANS.items() if any(ref() is None for ref, _kc, _dx in v[3].values())]:
+            del _PACK_PLANS[k]
         plan = _PACK_PLANS[key] = (items, len(rows), tiles, bufs)
+    if _PLAN_HOLDERS:
+        for held in _PLAN_HOLDERS:
+            if not any(h is plan for h in held):
+                held.append(plan)
     items, n, tiles, bufs = plan
     check(_lib.load().advhip_pack_weights_multi_f32(ptr(items), n, tiles, stream(ws[0])), "pack_weights_multi")
     _STEP_PACKS.clear()
@@ -186,6 +197,24 @@ def step_packs(convs) -> None:
 
 def end_step_packs() -> None:
     _STEP_PACKS.clear()
+
+
+_PLAN_HOLDERS: list = []
+
+
+class hold_plans:
+    """`with hold_plans() as held:` -- every pack plan step_packs() uses inside the block is appended to the list `held`
+    (strong references to its item table and operand buffers).  A graph capture keeps that list for as long as the graph lives:
+    replays write the packed weights into, and read GEMM operands from, exactly those buffers."""
+
+    def __enter__(self):
+        self.held: list = []
+        _PLAN_HOLDERS.append(self.held)
+        return self.held
+
+    def __exit__(self, *exc):
+        _PLAN_HOLDERS[:] = [h for h in _PLAN_HOLDERS if h is not self.held]
+        return False
 
 
 def _step_dx(weight: torch.Tensor) -> Optional[torch.Tensor]:
@@ -629,12 +658,13 @@ class _FFNBlockCN(torch.autograd.Function):
 PENDING_COUNTERS: list = []  # BatchNorm1d.num_batches_tracked tensors whose += 1 is still owed
 
 
-def flush_counters() -> None:
+def flush_counters(discard: bool = False) -> None:
     """num_batches_tracked += 1 for every BatchNorm layer that ran through _FocusAttnBlockCN since the last call: one
-    multi-tensor launch instead of one per layer (MGFNModel.forward calls this after the body)."""
-    if PENDING_COUNTERS:
+    multi-tensor launch instead of one per layer (MGFNModel.forward calls this after the body; `discard`: a forward that
+    raised drops what it queued instead of billing it to a later, unrelated forward)."""
+    if PENDING_COUNTERS and not discard:
         torch._foreach_add_(PENDING_COUNTERS, 1)
-        PENDING_COUNTERS.clear()
+    PENDING_COUNTERS.clear()
 
 
 class _FocusAttnBlockCN(torch.autograd.Function):

@@ -366,12 +366,14 @@ class MGFNModel(MGFNPreTrainedModel):
             mgfn_ops.invalidate_caches()  # the weights are about to be updated: no cached packed copy may outlive this pass
             if x.is_cuda and x.dtype == torch.float32 and x.device.index == torch.cuda.current_device():
                 mgfn_ops.step_packs(self._gemm_convs())  # ... and every GEMM layer's packed operand comes from one launch
+        ok = False
         try:
             # internal layout (C, B, T); `outputs` is returned in the reference's (B, C, T) shape (a view)
             y = self.layers(self.amplifier(x))
+            ok = True
         finally:
             mgfn_ops.end_step_packs()
-        mgfn_ops.flush_counters()  # (the BatchNorm layers' num_batches_tracked += 1, all in one launch)
+            mgfn_ops.flush_counters(discard=not ok)  # (the BatchNorm layers' num_batches_tracked += 1, all in one launch)
         return MGFNModelOutput(outputs=y.permute(1, 0, 2))
 
     def _gemm_convs(self):

@@ -185,6 +185,23 @@ def splitk_counters(dev: torch.device) -> torch.Tensor:
     return cnt
 
 
+def reset_stream_state(dev: Optional[torch.device] = None) -> None:
+    """Forget the self-resetting counter block and the zero-initialised workspace of the current stream (of `dev`, default: the
+    current device).  Those are zero-filled once and trusted to be left zero by every launch; a launch that did not run to its
+    end -- an entry point that reported an error, a graph capture that was abandoned after it recorded the zero-fill -- may
+    have broken that promise, so the next call allocates and zero-fills again.  `_lib.check` calls this on every reported error;
+    call it yourself after abandoning a capture."""
+    if not torch.cuda.is_available():
+        return
+    d = torch.device("cuda", torch.cuda.current_device()) if dev is None else dev
+    key = (d, torch.cuda.current_stream(d).cuda_stream)
+    _SPLITK_COUNTERS.pop(key, None)
+    _ZERO_WORKSPACES.pop(key, None)
+
+
+_lib.ON_FAILURE.append(reset_stream_state)
+
+
 def batch_stride(t: torch.Tensor) -> int:
     """Elements between consecutive samples of an NCDHW tensor that is contiguous per sample: a contiguous tensor,
     or a channel slice `wide[:, a:b]` of one (the kernels take the batch stride; everything inside a sample must be

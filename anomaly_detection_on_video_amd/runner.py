@@ -263,7 +263,10 @@ class Trainer:
         # the step as one HIP graph once the (fixed) batch shape has been seen a few times (train_graph.py); ADV_TRAIN_GRAPH=0:
         # always the eager loop
         graphed = None
+        # (only for the stock training_step: a subclass that overrides it -- its own loss, its own logging -- keeps the eager loop,
+        # which calls it; the graphed step calls runner.model directly)
         if (os.environ.get("ADV_TRAIN_GRAPH", "1") == "1" and hasattr(runner, "training_batch")
+                and type(runner).training_step is VideoAnomalyDetectionRunner.training_step
                 and all(g.get("capturable", False) for g in optimizer.param_groups)):
             from .train_graph import GraphedTrainStep
 

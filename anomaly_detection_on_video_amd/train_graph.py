@@ -47,6 +47,9 @@ class GraphedTrainStep:
         self.static: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
         self.loss: Optional[torch.Tensor] = None
         self.replays = 0
+        self.captures = 0
+        self.held_plans: list = []          # mgfn_ops pack plans whose buffers the captured graph reads and writes
+        self._stamp: Optional[Tuple] = None  # what the graph baked in besides shapes: parameter addresses, optimizer scalars
         if overlap and torch.cuda.is_available():
             mgfn_ops.ensure_side_stream()  # (streams cannot be created inside a capture)
 
@@ -61,6 +64,18 @@ class GraphedTrainStep:
         self.optimizer.step()
         return loss
 
+    MAX_CAPTURES = 4  # hyper-parameters that keep changing (a per-step LR schedule): after this many captures the step stays eager
+
+    def _baked(self) -> Tuple:
+        """Everything a captured graph holds by value or by address: the parameters' storage (a `.data =` / `.to()` moves it)
+        and the optimizer's scalar hyper-parameters (the fused capturable Adam takes lr / betas / eps / weight_decay as kernel
+        arguments) and the clip value.  A replay with a different stamp would train with stale numbers or touch freed memory:
+        __call__ compares and captures again."""
+        groups = tuple((float(g["lr"]) if not torch.is_tensor(g["lr"]) else ("t", g["lr"].data_ptr()), tuple(g.get("betas", ())), g.get("eps"),
+                        g.get("weight_decay"), g.get("amsgrad"), g.get("maximize"), tuple(p.data_ptr() for p in g["params"]))
+                       for g in self.optimizer.param_groups)
+        return (groups, self.clip, tuple(p.data_ptr() for p in self.model.parameters()))
+
     def _finish(self) -> None:
         mgfn_ops.invalidate_caches()  # (fused / captured optimizers do not move version counters)
         if self.after_step is not None:
@@ -68,6 +83,12 @@ class GraphedTrainStep:
 
     def __call__(self, video: torch.Tensor, abnormal_labels: torch.Tensor, normal_labels: torch.Tensor) -> torch.Tensor:
         key = (tuple(video.shape), tuple(abnormal_labels.shape), tuple(normal_labels.shape))
+        if self.graph is not None and key == self._key and self._baked() != self._stamp:
+            # a parameter moved or an optimizer scalar changed since the capture: the graph is stale -> capture again below
+            # (or, after MAX_CAPTURES of them, keep to the eager step, which reads everything live)
+            self.graph, self.static, self.loss, self.held_plans = None, None, None, []
+            if self.captures >= self.MAX_CAPTURES:
+                self.eager_left = 1 << 62
         if self.graph is not None and key == self._key:
             for dst, src in zip(self.static, (video, abnormal_labels, normal_labels)):
                 dst.copy_(src)
@@ -86,9 +107,11 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.optimizer.zero_grad(set_to_none=True)  # the captured backward allocates the gradients in the graph's pool
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with mgfn_ops.hold_plans() as held, torch.cuda.graph(graph):
             loss = self._step(*self.static)
         self.graph, self.loss = graph, loss.detach()
+        self.held_plans, self._stamp = held, self._baked()
+        self.captures += 1
         self.graph.replay()
         self.replays += 1
         self._finish()

@@ -10,8 +10,50 @@ one JSON object per line on stdout {"rc": int, "stdout": str, "stderr": str}.  E
 """
 import json
 import os
+import signal
 import subprocess
 import sys
+import tempfile
+
+
+def run_group(argv, env, cwd, timeout):
+    """Run argv as the leader of its OWN session / process group with its output in temporary files (not pipes: a grandchild
+    that survives would keep a pipe open and block the reader for ever).  On timeout the WHOLE group is killed -- the rank
+    processes of a torch.distributed.run launch are grandchildren, and they are the ones that hang in a collective -- and
+    waited for; rc -9 and the captured tail come back."""
+    with tempfile.TemporaryFile("w+b") as out, tempfile.TemporaryFile("w+b") as err:
+        p = subprocess.Popen(argv, env=env, cwd=cwd, stdout=out, stderr=err, stdin=subprocess.DEVNULL, start_new_session=True)
+        timed_out = False
+        try:
+            rc = p.wait(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            timed_out = True
+            for sig, grace in ((signal.SIGTERM, 10), (signal.SIGKILL, 30)):
+                try:
+                    os.killpg(p.pid, sig)  # (start_new_session: pgid == pid of the leader)
+                except ProcessLookupError:
+                    break
+                try:
+                    p.wait(timeout=grace)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+            try:  # stragglers of the group that outlived its leader
+                os.killpg(p.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            rc = -9
+
+        def tail(f):
+            f.seek(0, os.SEEK_END)
+            n = f.tell()
+            f.seek(max(0, n - 20000))
+            return f.read().decode("utf-8", "replace")
+
+        so, se = tail(out), tail(err)
+    if timed_out:
+        se += f"\n[launcher] timeout after {timeout} s: process group {p.pid} killed"
+    return {"rc": rc, "stdout": so, "stderr": se}
 
 
 def main() -> int:
@@ -25,11 +67,9 @@ def main() -> int:
         for k in req.get("unset") or []:
             env.pop(k, None)
         try:
-            p = subprocess.run(req["argv"], env=env, cwd=req.get("cwd"), capture_output=True, text=True, timeout=req.get("timeout", 600))
-            rep = {"rc": p.returncode, "stdout": p.stdout[-20000:], "stderr": p.stderr[-20000:]}
-        except subprocess.TimeoutExpired as e:
-            rep = {"rc": -9, "stdout": (e.stdout or b"").decode("utf-8", "replace")[-20000:] if isinstance(e.stdout, bytes) else (e.stdout or "")[-20000:],
-                   "stderr": "timeout"}
+            rep = run_group(req["argv"], env, req.get("cwd"), req.get("timeout", 600))
+        except Exception as e:  # (a bad command line must not take the helper down with it)
+            rep = {"rc": -1, "stdout": "", "stderr": f"[launcher] {type(e).__name__}: {e}"}
         sys.stdout.write(json.dumps(rep) + "\n")
         sys.stdout.flush()
     return 0

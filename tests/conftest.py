@@ -43,7 +43,10 @@ def launch_fresh(argv, env=None, unset=(), timeout=600, cwd=None):
         raise RuntimeError("the launcher helper is not running (no /dev/kfd at session start?)")
     _LAUNCHER.stdin.write(json.dumps({"argv": list(argv), "env": dict(env or {}), "unset": list(unset), "timeout": timeout, "cwd": cwd or REPO}) + "\n")
     _LAUNCHER.stdin.flush()
-    return json.loads(_LAUNCHER.stdout.readline())
+    line = _LAUNCHER.stdout.readline()
+    if not line:
+        raise RuntimeError(f"the launcher helper died (exit code {_LAUNCHER.poll()}) while running {list(argv)[:4]}...")
+    return json.loads(line)
 
 
 def pytest_collection_modifyitems(config, items):

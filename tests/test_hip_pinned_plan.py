@@ -48,6 +48,22 @@ def scorer():
     return s.eval().to(_dev())
 
 
+@pytest.fixture(autouse=True)
+def _split_k_counters_left_zero():
+    """Every launch must leave the self-resetting arrival counters of its stream zero (include/advhip.h,
+    advhip_conv3d_epilogue.splitk_counters): a word left non-zero -- an unfinished reduction, a tile index past the block --
+    would make the next split-K launch on that stream miss its last arriver.  Checked after every test of this file, on
+    every (device, stream) block the process has handed out."""
+    yield
+    from anomaly_detection_on_video_amd import ops
+
+    torch.cuda.synchronize()
+    for key, cnt in ops._SPLITK_COUNTERS.items():
+        assert int(cnt.abs().sum()) == 0, f"arrival counters of stream {key} left non-zero"
+    for key, ws in ops._ZERO_WORKSPACES.items():
+        assert int(ws[:16384].view(torch.int32).abs().sum()) == 0, f"NT-GEMM arrival counters of stream {key} left non-zero"
+
+
 def _tiled_input(batch: int, seed: int):
     g = np.load(os.path.join(GOLDEN, "i3d_fullnet.npz"))
     x2 = synth_input((2, 3, 16, 224, 224), seed)
@@ -275,4 +291,14 @@ def test_split_k_counters_caller_owned_block_and_memset_form_agree():
             _lib.check(lib.advhip_conv3d_bn_act_f32(C.byref(d), _lib.ptr(x), _lib.ptr(pc.w_packed), _lib.ptr(ops.ensure_ktab(pc, (t, h, w))),
                                                     _lib.ptr(pc.scale), _lib.ptr(pc.shift), None, _lib.ptr(y), _lib.ptr(ws), need, _lib.stream()), "memset form")
             assert torch.equal(y, got)
+            # a caller's block that is too small for this launch's tiles is not used: the launch falls back to the workspace
+            # head + memset (never indexes past the block), and the small block stays untouched
+            small = torch.full((4,), 7, device=dev, dtype=torch.int32)
+            ws.fill_(float("nan"))
+            y2 = torch.empty_like(got)
+            ep = _lib.ConvEpilogue(None, None, None, None, None, _lib.ptr(small), small.numel() * 4)
+            _lib.check(lib.advhip_conv3d_bn_act_ex_f32(C.byref(d), _lib.ptr(x), 0, _lib.ptr(pc.w_packed), _lib.ptr(ops.ensure_ktab(pc, (t, h, w))),
+                                                       _lib.ptr(pc.scale), _lib.ptr(pc.shift), None, _lib.ptr(y2), 0, C.byref(ep), _lib.ptr(ws), need,
+                                                       _lib.stream()), "small counter block")
+            assert torch.equal(y2, got) and bool((small == 7).all())
             assert rel_err(got.cpu(), ops.conv3d_bn_act(x, pc, relu=True, algo=algo, splits=1).cpu()) < 2e-5
