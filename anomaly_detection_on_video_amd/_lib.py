@@ -37,12 +37,16 @@ BF16X3_ALGOS = tuple(ALGO_BF16X3_BASE + a for a in (5, 6))
 ALGO_DMA2_BASE = 160  # + tile id: LDS-DMA kernel, 2-deep ring (less LDS, more resident workgroups)
 DMA2_ALGOS = tuple(ALGO_DMA2_BASE + a for a in (1, 2, 3, 4, 6, 7, 8))
 ALGO_TSPAN_128x64 = 192  # (kt,1,1) convs: 128x64 tile of 2 or 4 frames x flattened spatial positions
+ALGO_PERSIST_BASE = 224  # + tile id (2: 128x64, 3: 64x64) + 8 * (workgroups per CU - 1): persistent LDS-DMA kernel, unsplit 1x1x1 stride-1 convs
+PERSIST_ALGOS = tuple(ALGO_PERSIST_BASE + t + 8 * (w - 1) for w in (1, 2, 3) for t in (2, 3, 6, 7))
 
 
 def algo_tile(algo: int):
     """(BM, BN, BK) of an implicit-GEMM algorithm id."""
     if algo == ALGO_TSPAN_128x64:
         return (128, 64, 16)
+    if ALGO_PERSIST_BASE <= algo < ALGO_PERSIST_BASE + 32:
+        return (128 if (algo - ALGO_PERSIST_BASE) & 7 in (2, 6) else 64, 64, 16)
     if algo >= ALGO_DMA2_BASE:
         algo -= ALGO_DMA2_BASE
     if algo >= ALGO_BF16X3_BASE:
@@ -79,6 +83,10 @@ class ConvEpilogue(C.Structure):
 
 class ColsumItem(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int32), ("period", C.c_int32)]
+
+
+class AdamItem(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("param", "grad", "exp_avg", "exp_avg_sq", "step")] + [("n", C.c_int64)]
 
 
 class NtItem(C.Structure):
@@ -150,6 +158,7 @@ SIGNATURES = {
     "advhip_amp_combine_bwd_f32": (C.c_int, [_P, _P, _L, C.c_float, _P, _P, _P, _P, _I, _L, _I, _P]),
     "advhip_colsum_f32": (C.c_int, [_P, _P, _L, _I, _P]),
     "advhip_colsum_group_f32": (C.c_int, [C.POINTER(ColsumItem), _I, _P]),
+    "advhip_adam_multi_f32": (C.c_int, [C.POINTER(AdamItem), _I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
     "advhip_pack_item_tiles": (C.c_int64, [_I, _I, _I, _I]),
     "advhip_pack_weights_multi_f32": (C.c_int, [_P, _I, _I, _P]),
     "advhip_unfold3_f32": (C.c_int, [_P, _P, _I, _L, _I, _P]),

@@ -1430,6 +1430,377 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
 }
 
 // ================================================================================================
+// Persistent, wave-specialised form of the LDS-DMA kernel for unsplit 1x1x1 stride-1 convs on 16-byte aligned rows
+// (ConvArgs::a16): the `conv3` (+ residual) launches of every Bottleneck (src/i3d.py:85-89, 108-121) and the k = 1 `conv1`s.
+// Their K is 64-512, i.e. 4-32 k-tiles per output tile: in the one-tile-per-workgroup kernel above a tile's life is index
+// arithmetic, ring fill, a short MFMA run and then the epilogue's residual round trip, every `buffer_load ... lds` a wave issues
+// holds up that wave's own MFMA stream, and the kernel lives on eight resident waves per SIMD covering for each other
+// (profiles/r03_final_*: 40-58 % MFMA-busy on these launches against 82 % for the stem).  Here:
+//   * a launch is W x (compute units) workgroups of EIGHT waves that stay; each walks a contiguous share of its XCD's part of the
+//     output tiles (n fastest: the n-tiles of an m-tile re-read the same activation rows from the XCD's L2);
+//   * waves 0-3 only feed the matrix pipe: barrier, fragment reads, MFMAs.  At the end of a tile they apply scale / shift and
+//     drop the tile into an LDS staging area (8 ds_write_b128 per lane), then go on with the next tile;
+//   * waves 4-7 are the loaders and the epilogue.  Every k-tile interval they issue the LDS-DMA loads of the operand ring --
+//     which runs ACROSS tile boundaries, NS - 1 k-tiles ahead, so no tile after a workgroup's first waits for a ring fill -- and
+//     wait (an exact count) for the NEXT k-tile to have landed before they arrive at the barrier that releases it.  One
+//     interval after a tile was staged they pick it up into registers and issue its residual loads; two intervals later
+//     (the loads have landed beside the other waves' MFMAs) they add, apply the activation and store whole 16-byte pieces of
+//     NCDHW rows;
+//   * the ONE barrier per k-tile that the ring needs anyway is all the synchronisation there is: both roles execute the same
+//     number of barriers; a staged tile is written after the barrier of its last k-tile and read after the next one.
+// Same operand layout, k order and accumulation chain as conv3d_igemm_dma_kernel (unsplit): bit-identical results.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_switch(int n) {  // s_waitcnt vmcnt(min(n, N)) for a wave-uniform n (the immediate needs a constant)
+  static_assert(N <= 40, "cases");
+  const int c = n < N ? (n < 0 ? 0 : n) : N;
+#define ADVHIP_VMCNT_CASE(I) \
+  case I: asm volatile("s_waitcnt vmcnt(" #I ")" ::: "memory"); break;
+  switch (c) {
+    ADVHIP_VMCNT_CASE(0) ADVHIP_VMCNT_CASE(1) ADVHIP_VMCNT_CASE(2) ADVHIP_VMCNT_CASE(3) ADVHIP_VMCNT_CASE(4) ADVHIP_VMCNT_CASE(5) ADVHIP_VMCNT_CASE(6)
+    ADVHIP_VMCNT_CASE(7) ADVHIP_VMCNT_CASE(8) ADVHIP_VMCNT_CASE(9) ADVHIP_VMCNT_CASE(10) ADVHIP_VMCNT_CASE(11) ADVHIP_VMCNT_CASE(12) ADVHIP_VMCNT_CASE(13)
+    ADVHIP_VMCNT_CASE(14) ADVHIP_VMCNT_CASE(15) ADVHIP_VMCNT_CASE(16) ADVHIP_VMCNT_CASE(17) ADVHIP_VMCNT_CASE(18) ADVHIP_VMCNT_CASE(19) ADVHIP_VMCNT_CASE(20)
+    ADVHIP_VMCNT_CASE(21) ADVHIP_VMCNT_CASE(22) ADVHIP_VMCNT_CASE(23) ADVHIP_VMCNT_CASE(24) ADVHIP_VMCNT_CASE(25) ADVHIP_VMCNT_CASE(26) ADVHIP_VMCNT_CASE(27)
+    ADVHIP_VMCNT_CASE(28) ADVHIP_VMCNT_CASE(29) ADVHIP_VMCNT_CASE(30) ADVHIP_VMCNT_CASE(31) ADVHIP_VMCNT_CASE(32) ADVHIP_VMCNT_CASE(33) ADVHIP_VMCNT_CASE(34)
+    ADVHIP_VMCNT_CASE(35) ADVHIP_VMCNT_CASE(36) ADVHIP_VMCNT_CASE(37) ADVHIP_VMCNT_CASE(38) ADVHIP_VMCNT_CASE(39) ADVHIP_VMCNT_CASE(40)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef ADVHIP_VMCNT_CASE
+}
+
+// (registers: two 8-wave workgroups per CU for the 128-row tile = 4 waves per SIMD = 128 VGPRs; three for the 64-row one)
+template <int BM, int BN, int NS, bool DBG = false>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BM == 128 ? 4 : 6, 8)))
+void conv1x1_persist_kernel(const ConvArgs a) {
+  constexpr int BK = 16;
+  using Cfg = IgemmCfg<BM, BN, BK>;
+  using D = DmaCfg<BM, BN, BK>;
+  constexpr int FM = Cfg::FM, FN = Cfg::FN, LB = D::LB, KS = BK / 4;
+  static_assert(NS == 2, "LDS ring depth (the depth of the prefetch is the loader waves' register sets)");
+  static_assert(BN == 64 && (BM == 128 || BM == 64), "tile");
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  constexpr int RING = NS * D::STAGE;
+  constexpr int RPI16 = 256 / BM, LA16 = BK * BM / 1024;  // 16-byte A pieces: k-rows per wave-instruction, instructions per loader wave and k-tile
+  constexpr int LPRB = BN / 4, RPW = 64 / LPRB;
+  constexpr int PER_TILE = LA16 + LB;                      // LDS-DMA instructions per loader wave and k-tile
+  constexpr int SLOTS = BM / 4;                            // float4 slots per staged channel row
+  constexpr int EPT = BM * BN / 4 / 256;                   // float4 per epilogue thread and tile (8 or 4)
+  constexpr int ROWS_PER_PASS = 256 / SLOTS;               // channel rows the 256 epilogue threads cover per pass
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int A16_BYTES = 16;  // (the host pass only parses this body; see gemm_kk_dma_kernel)
+#else
+  constexpr int A16_BYTES = 4;
+#endif
+  __shared__ __attribute__((aligned(16))) float smem[RING + BM * BN];
+  // staging: [BN channel rows][BM positions], the float4 slots of row n rotated by n (bank spread): never a ring stage
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // this workgroup's tiles: XCD x (= blockIdx % 8, the dispatch order) owns a contiguous eighth of the linear tile order
+  // L = tile_m * tiles_n + tile_n, workgroup j of the XCD's gridDim / 8 a contiguous part of that
+  const int NT = a.tiles_m * a.tiles_n;
+  const int gx = (int)(gridDim.x >> 3), xcd = (int)(blockIdx.x & 7), jx = (int)(blockIdx.x >> 3);
+  const int lo = (int)(((long long)NT * xcd) >> 3), hi = (int)(((long long)NT * (xcd + 1)) >> 3);
+  const int t0 = lo + (int)(((long long)(hi - lo) * jx) / gx), t1 = lo + (int)(((long long)(hi - lo) * (jx + 1)) / gx);
+  if (t0 >= t1) return;
+  const int nk = a.Kpad / BK;
+  const int total = (t1 - t0) * nk;  // k-tiles of this workgroup, all its output tiles one after the other
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+  const unsigned stg0 = lds0 + (unsigned)RING * 4u;
+
+  if (wave < 4) {
+    // ---------------------------------------------------------------- MFMA waves
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    const unsigned a_addr0 = lds0 + (unsigned)(lg * BM + wm * Cfg::WM + FM * li) * 4u;
+    const unsigned b_addr0 = lds0 + (unsigned)(BK * BM + lg * BN + wn * Cfg::WN + FN * li) * 4u;
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int jn = 0; jn < FN; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int stage) {
+      const unsigned aa = a_addr0 + (unsigned)(stage * D::STAGE) * 4u;
+      const unsigned ba = b_addr0 + (unsigned)(stage * D::STAGE) * 4u;
+      Frag<FM> fa[2];
+      Frag<FN> fb[2];
+      lds_read<FM, 0>(fa[0], aa);
+      lds_read<FN, 0>(fb[0], ba);
+      auto body = [&](auto ks_c) {
+        constexpr int ks = decltype(ks_c)::value;
+        if constexpr (ks + 1 < KS) {
+          lds_read<FM, (ks + 1) * 4 * BM * 4>(fa[(ks + 1) & 1], aa);
+          lds_read<FN, (ks + 1) * 4 * BN * 4>(fb[(ks + 1) & 1], ba);
+          lds_wait<2>(fa[ks & 1], fb[ks & 1]);
+        } else {
+          lds_wait<0>(fa[ks & 1], fb[ks & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int jn = 0; jn < FN; ++jn)
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks & 1].v[i], fb[ks & 1].v[jn], acc[i][jn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      [&]<int... I>(std::integer_sequence<int, I...>) { (body(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, KS>{});
+    };
+
+    // scale / shift of this lane's FN channels of the current tile (these waves' only global loads: nothing else counts on their vmcnt)
+    float sc[FN], sf[FN];
+    auto load_scale = [&](int L) {
+      const int tm = (int)a.dTilesN.div((unsigned)L), tn = L - tm * a.tiles_n;
+#pragma unroll
+      for (int jn = 0; jn < FN; ++jn) {
+        const int n = tn * BN + wn * Cfg::WN + FN * li + jn;
+        sc[jn] = a.scale[n];
+        sf[jn] = a.shift[n];
+      }
+    };
+    load_scale(t0);
+    int stage = 0, kt = 0, tile = t0;
+    unsigned long long dbg_bar = 0, dbg_t0 = 0, dbg_start = 0;
+    if constexpr (DBG) dbg_start = __builtin_amdgcn_s_memtime();
+    for (int q = 0; q < total; ++q) {
+      if constexpr (DBG) dbg_t0 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_barrier" ::: "memory");  // k-tile q is in LDS (the loaders waited for it before they arrived)
+      if constexpr (DBG) dbg_bar += __builtin_amdgcn_s_memtime() - dbg_t0;
+      compute(stage);
+      stage = stage == NS - 1 ? 0 : stage + 1;
+      if (++kt == nk) {
+        kt = 0;
+        // hand the tile to the epilogue waves: accumulator element acc[jm][jn][r] of lane (li, lg) is output (m, n) =
+        // (wm*WM + FM*(4 lg + r) + jm, wn*WN + FN*li + jn) -- a lane holds 4 FM consecutive m of channel row n: whole float4 slots.
+        // (They read the previous tile's staging in the interval after this tile's FIRST barrier: long done.  asm stores: hipcc
+        // would put `s_waitcnt vmcnt(0)` in front of its own LDS stores in a kernel with LDS-DMA loads pending.)
+#pragma unroll
+        for (int jn = 0; jn < FN; ++jn) {
+          const int n = wn * Cfg::WN + FN * li + jn;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if constexpr (FM == 4) {
+              const int slot = (wm * Cfg::WM + 16 * lg + 4 * r) >> 2;
+              const unsigned addr = stg0 + (unsigned)(n * BM + (((slot ^ n) & (SLOTS - 1)) << 2)) * 4u;
+              const f32x4 t = {acc[0][jn][r] * sc[jn] + sf[jn], acc[1][jn][r] * sc[jn] + sf[jn], acc[2][jn][r] * sc[jn] + sf[jn],
+                               acc[3][jn][r] * sc[jn] + sf[jn]};
+              asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(t) : "memory");
+            } else {
+              using f32x2 = __attribute__((ext_vector_type(2))) float;
+              const int m = wm * Cfg::WM + 8 * lg + 2 * r;  // FM == 2: two consecutive m per (r): half a slot
+              const int slot = m >> 2;
+              const unsigned addr = stg0 + (unsigned)(n * BM + (((slot ^ n) & (SLOTS - 1)) << 2) + (m & 3)) * 4u;
+              const f32x2 t = {acc[0][jn][r] * sc[jn] + sf[jn], acc[1][jn][r] * sc[jn] + sf[jn]};
+              asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(t) : "memory");
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staged tile is in LDS before this wave reaches the next barrier
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int jn = 0; jn < FN; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (++tile < t1) load_scale(tile);
+      }
+    }
+    asm volatile("s_barrier" ::: "memory");  // the last tile is staged
+    if constexpr (DBG) {
+      if (tid == 0) {
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(a.y2) + (size_t)blockIdx.x * 8;
+        d[0] = __builtin_amdgcn_s_memtime() - dbg_start;
+        d[1] = dbg_bar;
+        d[2] = (unsigned long long)total;
+      }
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ loader + epilogue waves
+  // Operands go global -> registers -> LDS here (plain 16-byte buffer loads, PD k-tiles of them in flight per wave, then
+  // ds_write_b128 one interval before the k-tile is multiplied): an LDS-DMA instruction holds its issuing wave for ~500 cycles with
+  // one wave per SIMD issuing (in-kernel stamps, tools/persist_stamps.py: four loader waves moved 6 B/clk per CU with LDS-DMA,
+  // which made THEM the bottleneck); ordinary loads issue in a few cycles each and these waves have the registers to spare.  Every
+  // vector-memory operation of these waves is visible to hipcc, which counts its waits exactly (no LDS-DMA in the kernel: none of
+  // its conservative vmcnt(0) rules apply).
+  constexpr int PD = 3;  // k-tiles of operand loads in flight per loader wave (beyond the one being written to LDS)
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+  const int lw = wave - 4;
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+  const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+  const unsigned wvoff = (unsigned)((lane / LPRB) * a.Cout + (lane % LPRB) * 4) * 4u;
+  const int a_lane4 = (lane % (BM / 4)) * 4, a_lrow = lane / (BM / 4);
+  // the tile operands are being fetched for (runs PD k-tiles ahead of the one being multiplied)
+  int p_tile = t0, p_kt = 0, p_n0 = 0;
+  unsigned p_vbase = OOB;
+  auto set_prefetch_tile = [&](int L) __attribute__((always_inline)) {
+    const int tm = (int)a.dTilesN.div((unsigned)L), tn = L - tm * a.tiles_n;
+    p_n0 = tn * BN;
+    const int m4 = tm * BM + a_lane4;
+    p_vbase = OOB;
+    if (m4 < a.M) {
+      const int b4 = (int)a.dTHWo.div((unsigned)m4);
+      p_vbase = (unsigned)(b4 * a.x_bstride + (m4 - b4 * a.MP) + a_lrow * a.THW) * 4u;
+    }
+  };
+  set_prefetch_tile(t0);
+  u32x4 ra[PD][LA16], rb[PD][LB];
+  auto load_next = [&](auto d_c) __attribute__((always_inline)) {  // k-tile p_kt of tile p_tile into register set d, then advance
+    constexpr int d = decltype(d_c)::value;
+    const int k0 = p_kt * BK;
+#pragma unroll
+    for (int q = 0; q < LA16; ++q) {
+      const int g = lw * LA16 + q;
+      ra[d][q] = __builtin_amdgcn_raw_buffer_load_b128(rx, p_vbase, (k0 + g * RPI16) * a.THW * 4, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < LB; ++q) {
+      const int row0 = (lw * LB + q) * RPW;
+      rb[d][q] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, ((k0 + row0) * a.Cout + p_n0) * 4, 0);
+    }
+    if (++p_kt == nk) {
+      p_kt = 0;
+      if (++p_tile < t1) set_prefetch_tile(p_tile);
+    }
+  };
+  auto write_stage = [&](auto d_c, int stage) __attribute__((always_inline)) {  // register set d -> ring stage `stage` (the image the LDS-DMA form writes: linear in the lane)
+    constexpr int d = decltype(d_c)::value;
+    float* As = smem + stage * D::STAGE;
+    float* Bs = As + BK * BM;
+#pragma unroll
+    for (int q = 0; q < LA16; ++q) {
+      const int g = lw * LA16 + q;
+      *reinterpret_cast<u32x4*>(As + g * RPI16 * BM + lane * 4) = ra[d][q];
+    }
+#pragma unroll
+    for (int q = 0; q < LB; ++q) {
+      const int row0 = (lw * LB + q) * RPW;
+      *reinterpret_cast<u32x4*>(Bs + row0 * BN + lane * 4) = rb[d][q];
+    }
+  };
+
+  const int e = tid - 256;                       // 0..255
+  const int slot = e % SLOTS, row0 = e / SLOTS;  // this thread's float4 slot and first channel row of the staged tile
+  const bool vec = a.vw == 4;
+  const bool res_vec = vec && a.res != nullptr;  // (wave-uniform: kernel arguments)
+  f32x4 rv[EPT];
+  int em = 0, eb = 0, epp = 0, en0 = 0;  // the tile being finished: m of this thread's slot, its sample / position, the tile's first channel
+  bool eok = false;
+  auto pick_up = [&](int L) __attribute__((always_inline)) {  // the staged tile's coordinates; its residual loads issued
+    const int tm = (int)a.dTilesN.div((unsigned)L), tn = L - tm * a.tiles_n;
+    en0 = tn * BN;
+    em = tm * BM + slot * 4;
+    eok = em < a.M;
+    eb = 0; epp = 0;
+    if (eok) { eb = (int)a.dTHWo.div((unsigned)em); epp = em - eb * a.MP; }
+    if (res_vec) {
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        const int n = en0 + row0 + ROWS_PER_PASS * i;
+        const float* src = eok ? a.res + ((size_t)(eb * a.Cout + n) * a.THWo + epp) : a.res;  // (rows past M: the tensor's first bytes, never used)
+        rv[i] = *reinterpret_cast<const f32x4*>(src);
+      }
+    }
+  };
+  // two intervals later (the staged tile stays put until the end of its successor's LAST k-tile interval; nk >= 4): staged values
+  // + residual, activation, stores -- one channel row at a time, so that only the residual prefetch holds registers meanwhile
+  auto finish = [&]() __attribute__((always_inline)) {
+    if (!eok) return;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int nl = row0 + ROWS_PER_PASS * i, n = en0 + nl;
+      const f32x4 vv = *reinterpret_cast<const f32x4*>(smem + RING + nl * BM + (((slot ^ nl) & (SLOTS - 1)) << 2));
+      const size_t o = (size_t)(eb * a.Cout + n) * a.THWo + epp;                    // dense: residual
+      const size_t oy = (size_t)eb * a.y_bstride + (size_t)n * a.THWo + epp;        // output proper
+      float x4[4] = {vv[0], vv[1], vv[2], vv[3]};
+      if (vec) {
+        if (a.res) { x4[0] += rv[i][0]; x4[1] += rv[i][1]; x4[2] += rv[i][2]; x4[3] += rv[i][3]; }
+        if (!DBG && a.y2) vec_store<4>(a.y2 + oy, x4);
+        if (a.relu) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) x4[c] = act_apply(a.relu, x4[c]);
+        }
+        vec_store<4>(a.y + oy, x4);
+      } else {
+        // rows that are not a multiple of 4 positions long (or unaligned pointers): one position at a time; positions >= THWo of a
+        // sample are the padding of the M index space (ConvArgs::MP)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (epp + c < a.THWo) {
+            float val = x4[c];
+            if (a.res) val += a.res[o + c];
+            if (!DBG && a.y2) a.y2[oy + c] = val;
+            if (a.relu) val = act_apply(a.relu, val);
+            a.y[oy + c] = val;
+          }
+        }
+      }
+    }
+  };
+
+  // prologue: k-tiles 0 .. PD-1 on their way to registers, k-tile 0 in ring stage 0 before the first barrier
+  int loaded = 0;
+  [&]<int... I>(std::integer_sequence<int, I...>) {
+    ((loaded < total ? (load_next(std::integral_constant<int, I>{}), ++loaded, 0) : 0), ...);
+  }(std::make_integer_sequence<int, PD>{});
+  write_stage(std::integral_constant<int, 0>{}, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  {
+    constexpr int fin = 2;  // the k-tile interval (of the NEXT tile) in which a picked-up tile is finished (nk >= 4: the launcher checks)
+    int kt = 0, tile = t0;
+    bool have = false;     // a finished tile of this workgroup is waiting in the staging area / in this thread's registers
+    unsigned long long dbg_bar = 0, dbg_vm = 0, dbg_t0 = 0, dbg_start = 0;
+    if constexpr (DBG) dbg_start = __builtin_amdgcn_s_memtime();
+    // one interval = the time between two barriers; k-tile q lives in register set q % PD until the interval before it is multiplied.
+    // (The register set is picked by a wave-uniform branch around the few load / ds_write instructions, so that the epilogue code
+    // below exists once.)
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    using c2 = std::integral_constant<int, 2>;
+    static_assert(PD == 3, "register sets");
+    int dq = 0;  // q % PD
+    for (int q = 0; q < total; ++q) {
+      if constexpr (DBG) dbg_t0 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_barrier" ::: "memory");  // releases k-tile q to the MFMA waves; they are done with ring stage (q - 1) & 1
+      if constexpr (DBG) dbg_bar += __builtin_amdgcn_s_memtime() - dbg_t0;
+      if (loaded < total) {  // (set dq held k-tile q: written to LDS in the previous interval)
+        if (dq == 0) load_next(c0{});
+        else if (dq == 1) load_next(c1{});
+        else load_next(c2{});
+        ++loaded;
+      }
+      if (have) {
+        if (kt == 0) pick_up(tile - 1);  // staged after the previous tile's last barrier, visible since this one
+        if (kt == fin) finish();
+      }
+      const int dn = dq == PD - 1 ? 0 : dq + 1;
+      if (q + 1 < total) {  // k-tile q + 1 into the stage the MFMA waves have just left
+        if constexpr (DBG) dbg_t0 = __builtin_amdgcn_s_memtime();
+        if (dn == 0) write_stage(c0{}, (q + 1) & 1);
+        else if (dn == 1) write_stage(c1{}, (q + 1) & 1);
+        else write_stage(c2{}, (q + 1) & 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (DBG) dbg_vm += __builtin_amdgcn_s_memtime() - dbg_t0;
+      }
+      dq = dn;
+      if (++kt == nk) { kt = 0; ++tile; have = true; }
+    }
+    asm volatile("s_barrier" ::: "memory");
+    if constexpr (DBG) {
+      if (tid == 256) {
+        unsigned long long* dd = reinterpret_cast<unsigned long long*>(a.y2) + (size_t)blockIdx.x * 8;
+        dd[4] = __builtin_amdgcn_s_memtime() - dbg_start;
+        dd[5] = dbg_bar;
+        dd[6] = dbg_vm;
+      }
+      return;
+    }
+    pick_up(t1 - 1);
+    finish();
+  }
+}
+
+// ================================================================================================
 // The stem on resized uint8 frames (F, FH, FW, 3), whole pixels at a time.  The byte-gather form above issues one
 // `buffer_load_ubyte ... lds` per (channel, tap) row and 64 positions -- as many LDS-DMA instructions as the fp32 kernel, and
 // the vector issue port those share with the MFMAs is what bounds that kernel (the extra v_cvt of the byte form then costs
@@ -2353,8 +2724,14 @@ struct Choice {
   int splits;  // >= 1
 };
 
+// persistent family: id = ADVHIP_ALGO_PERSIST_BASE + tile (2: 128 x 64, 3: 64 x 64) + 8 * (workgroups per CU - 1)
+static bool is_persist(int algo) { return algo >= ADVHIP_ALGO_PERSIST_BASE && algo < ADVHIP_ALGO_PERSIST_BASE + 32; }
+static int persist_tile(int algo) { return (algo - ADVHIP_ALGO_PERSIST_BASE) & 7; }
+static int persist_wgs_per_cu(int algo) { return ((algo - ADVHIP_ALGO_PERSIST_BASE) >> 3) + 1; }
+
 static void tile_of(int algo, int* BM, int* BN, int* BK) {
   if (algo == ADVHIP_ALGO_TSPAN_128x64) { *BM = 128; *BN = 64; *BK = 16; return; }
+  if (is_persist(algo)) { *BM = (persist_tile(algo) == 2 || persist_tile(algo) == 5 || persist_tile(algo) == 6) ? 128 : 64; *BN = 64; *BK = 16; return; }
   if (algo >= ADVHIP_ALGO_DMA2_BASE) algo -= ADVHIP_ALGO_DMA2_BASE;
   if (algo >= ADVHIP_ALGO_BF16X3_BASE) algo -= ADVHIP_ALGO_BF16X3_BASE;
   if (algo >= ADVHIP_ALGO_DMA4_BASE) algo -= ADVHIP_ALGO_DMA4_BASE;
@@ -2370,6 +2747,7 @@ static void tile_of(int algo, int* BM, int* BN, int* BK) {
 // (e.g. DMA_BASE + 5) are rejected up front: a launch switch that fell through would return OK with y unwritten.
 static bool instantiated(int algo) {
   if (algo == ADVHIP_ALGO_TSPAN_128x64) return true;
+  if (algo >= ADVHIP_ALGO_PERSIST_BASE) return is_persist(algo) && (persist_tile(algo) == 2 || persist_tile(algo) == 3 || persist_tile(algo) == 5 || persist_tile(algo) == 6 || persist_tile(algo) == 7);
   auto tile_in = [](int t, unsigned mask) { return t >= 1 && t <= 8 && ((mask >> t) & 1u); };
   constexpr unsigned ALL = 0x1FEu, NO5 = ALL & ~(1u << 5);
   if (algo >= ADVHIP_ALGO_DMA2_BASE) return tile_in(algo - ADVHIP_ALGO_DMA2_BASE, NO5);
@@ -2432,6 +2810,19 @@ namespace advhip {
 // the LDS-DMA kernel families reduce split-K partials inside the launch (no second kernel)
 static bool reduces_in_kernel(int algo) {
   return (algo >= ADVHIP_ALGO_DMA_BASE && algo < ADVHIP_ALGO_BF16X3_BASE) || algo >= ADVHIP_ALGO_DMA2_BASE;
+}
+
+// compute units of the current device (the persistent kernels size their grid from it)
+static int device_cus() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
 }
 // Split-K workspace: two-launch form = [splits][M*Cout] slabs in y's layout; in-kernel form = [tiles] arrival counters
 // (padded to 256 bytes) followed by [tiles][splits][BM*BN] fragment-major partial tiles.
@@ -2607,7 +2998,7 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
   long long Mv = M;
   bool a16pad = false;
   if (nocheck && d->st == 1 && d->sh == 1 && d->sw == 1 && a.THW % 4 != 0 && ((uintptr_t)x & 15) == 0 && c.splits == 1 &&
-      c.algo > ADVHIP_ALGO_DMA2_BASE && c.algo <= ADVHIP_ALGO_DMA2_BASE + 8 && !ln && y_preact == nullptr && dact_z == nullptr) {
+      ((c.algo > ADVHIP_ALGO_DMA2_BASE && c.algo <= ADVHIP_ALGO_DMA2_BASE + 8) || is_persist(c.algo)) && !ln && y_preact == nullptr && dact_z == nullptr) {
     a.MP = (a.THWo + 3) / 4 * 4;
     Mv = (long long)d->B * a.MP;
     if (Mv < (1ll << 31)) {
@@ -2700,6 +3091,25 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
   if (avg_out != nullptr) {
     hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, false, 2, EPI_AVG>), grid, dim3(256), 0, st, a);
     return check_launch("conv3d + mean");
+  }
+  if (is_persist(c.algo)) {
+    // workgroups that stay: `wgs_per_cu` per compute unit (a multiple of 8 in all, at most one per tile), each walking its share of the tiles
+    ADVHIP_REQUIRE(g.Kpad >= 64, "conv3d: the persistent kernels need K >= 64 (four k-tiles per output tile), got %d", g.K);
+    ADVHIP_REQUIRE(a.a16 != 0 && c.splits == 1 && !ln && dact_z == nullptr,
+                   "conv3d: the persistent kernels (algo %d) take unsplit 1x1x1 stride-1 convs on 16-byte aligned rows without the LayerNorm fold / "
+                   "GELU-backward operands (k=%d,%d,%d, splits=%d)", c.algo, d->kt, d->kh, d->kw, c.splits);
+    const long long nt = (long long)a.tiles_m * a.tiles_n;
+    long long g = (long long)persist_wgs_per_cu(c.algo) * device_cus();
+    if (g > nt) g = nt;
+    g = g / 8 * 8;
+    if (g < 8) g = 8;
+    const dim3 pgrid((unsigned)g);
+    switch (persist_tile(c.algo)) {  // (experiment: ring depth per id)
+      case 2: case 6: hipLaunchKernelGGL((conv1x1_persist_kernel<128, 64, 2>), pgrid, dim3(512), 0, st, a); break;
+      case 5: hipLaunchKernelGGL((conv1x1_persist_kernel<128, 64, 2, true>), pgrid, dim3(512), 0, st, a); break;  // (diagnostic: cycle stamps into y_preact)
+      default: hipLaunchKernelGGL((conv1x1_persist_kernel<64, 64, 2>), pgrid, dim3(512), 0, st, a); break;
+    }
+    return check_launch("conv3d persistent");
   }
   switch (c.algo) {
     case ADVHIP_ALGO_TSPAN_128x64:
@@ -3164,8 +3574,10 @@ static int gemm_nt_launch(const float* A, const float* B, float* C, int32_t M, i
                           int64_t ldc, int32_t splits, int64_t slab_stride, int32_t tile, float* rowsum_a, void* workspace,
                           int64_t workspace_bytes, void* stream, int64_t rowsum_slab_stride = 0) {
   ADVHIP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "gemm_nt: bad arguments");
-  ADVHIP_REQUIRE(K % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0,
-                 "gemm_nt: K=%d must be a multiple of 16 and the operands 16-byte aligned with row pitches that are multiples of 4", K);
+  // (row pitches need not be multiples of 4 floats: a 16-byte LDS-DMA piece takes any 4-byte aligned address on gfx950, tools/probe/ --
+  // the 2 049-float rows of the scorer's (positions, channels + magnitude) input are read as they are stored)
+  ADVHIP_REQUIRE(K % 16 == 0 && ((uintptr_t)A & 3) == 0 && ((uintptr_t)B & 3) == 0,
+                 "gemm_nt: K=%d must be a multiple of 16 and the operands 4-byte aligned", K);
   ADVHIP_REQUIRE(lda >= K && ldb >= K && ldc >= N, "gemm_nt: row pitch smaller than a row");
   const long long a_bytes = ((long long)(M - 1) * lda + K) * 4, b_bytes = ((long long)(N - 1) * ldb + K) * 4;
   ADVHIP_REQUIRE(a_bytes < 0xF0000000ll && b_bytes < 0xF0000000ll, "gemm_nt: operand above 3.75 GiB");

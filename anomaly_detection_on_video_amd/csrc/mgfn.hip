@@ -968,6 +968,89 @@ extern "C" int advhip_colsum_group_f32(const advhip_colsum_item* items, int32_t 
   return ADVHIP_OK;
 }
 
+// ---- Adam with L2-in-gradient weight decay over many parameter tensors in one launch (torch.optim.Adam's update rule,
+// /root/reference/src/runner.py:53-59; torch/optim/adam.py) -------------------------------------------------------------------
+//   g' = g + wd * p;  m = m + (1 - b1) (g' - m);  v = b2 v + (1 - b2) g'^2;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// t = *step (a device-side counter the caller has already incremented for this step; fp32 as torch's capturable Adam keeps it).
+// The item table travels in the kernel arguments (a launch inside a captured HIP graph replays it as is); a workgroup finds its
+// item by a scalar scan and updates ADAM_PER_BLOCK consecutive elements of it, 16 bytes per lane and access.
+constexpr int ADAM_MAX_ITEMS = 80, ADAM_PER_BLOCK = 4096;
+struct AdamItem {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  const float* step;
+  int n;
+  int block_begin;
+};
+struct AdamArgs {
+  AdamItem it[ADAM_MAX_ITEMS];
+  int n;
+  double lr, b1, b2;  // (doubles: 1 - beta and lr / (1 - beta^t) are formed in double and rounded once, as torch does in Python)
+  float eps, wd;
+};
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamArgs aa) {
+  int i = 0;
+  while (i + 1 < aa.n && (int)blockIdx.x >= aa.it[i + 1].block_begin) ++i;
+  const AdamItem& t = aa.it[i];
+  const int base = ((int)blockIdx.x - t.block_begin) * ADAM_PER_BLOCK;
+  const double st = (double)*t.step;
+  const float step_size = (float)(aa.lr / (1.0 - pow(aa.b1, st)));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow(aa.b2, st));
+  const float omb1 = (float)(1.0 - aa.b1), b2 = (float)aa.b2, omb2 = (float)(1.0 - aa.b2), eps = aa.eps, wd = aa.wd;
+  auto upd = [&](float& p, float g, float& m, float& v) {
+    g = g + wd * p;
+    m = m + omb1 * (g - m);
+    v = b2 * v + omb2 * g * g;
+    p = p - step_size * m / (sqrtf(v) / bc2_sqrt + eps);
+  };
+  const bool vec = ((((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0);
+#pragma unroll
+  for (int u = 0; u < ADAM_PER_BLOCK / 1024; ++u) {
+    const int e = base + u * 1024 + (int)threadIdx.x * 4;
+    if (e >= t.n) break;
+    if (vec && e + 4 <= t.n) {
+      float4 p = *reinterpret_cast<const float4*>(t.p + e), m = *reinterpret_cast<const float4*>(t.m + e), v = *reinterpret_cast<const float4*>(t.v + e);
+      const float4 g = *reinterpret_cast<const float4*>(t.g + e);
+      upd(p.x, g.x, m.x, v.x); upd(p.y, g.y, m.y, v.y); upd(p.z, g.z, m.z, v.z); upd(p.w, g.w, m.w, v.w);
+      *reinterpret_cast<float4*>(t.p + e) = p;
+      *reinterpret_cast<float4*>(t.m + e) = m;
+      *reinterpret_cast<float4*>(t.v + e) = v;
+    } else {
+      for (int k = e; k < e + 4 && k < t.n; ++k) {
+        float p = t.p[k], m = t.m[k], v = t.v[k];
+        upd(p, t.g[k], m, v);
+        t.p[k] = p; t.m[k] = m; t.v[k] = v;
+      }
+    }
+  }
+}
+
+extern "C" int advhip_adam_multi_f32(const advhip_adam_item* items, int32_t n_items, double lr, double beta1, double beta2, double eps,
+                                     double weight_decay, void* stream) {
+  ADVHIP_REQUIRE(items && n_items > 0, "adam_multi: bad arguments");
+  ADVHIP_REQUIRE(lr >= 0. && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0. && weight_decay >= 0.,
+                 "adam_multi: bad hyper-parameters (lr %g, betas %g %g, eps %g, weight_decay %g)", lr, beta1, beta2, eps, weight_decay);
+  for (int base = 0; base < n_items; base += ADAM_MAX_ITEMS) {
+    AdamArgs aa;
+    aa.n = std::min(ADAM_MAX_ITEMS, n_items - base);
+    aa.lr = lr; aa.b1 = beta1; aa.b2 = beta2; aa.eps = (float)eps; aa.wd = (float)weight_decay;
+    long long blocks = 0;
+    for (int i = 0; i < aa.n; ++i) {
+      const advhip_adam_item& s = items[base + i];
+      ADVHIP_REQUIRE(s.param && s.grad && s.exp_avg && s.exp_avg_sq && s.step && s.n > 0 && s.n < (1ll << 31), "adam_multi: item %d: bad arguments", base + i);
+      aa.it[i] = AdamItem{s.param, s.grad, s.exp_avg, s.exp_avg_sq, s.step, (int)s.n, (int)blocks};
+      blocks += (s.n + ADAM_PER_BLOCK - 1) / ADAM_PER_BLOCK;
+      ADVHIP_REQUIRE(blocks < (1ll << 31), "adam_multi: too many elements");
+    }
+    for (int i = aa.n; i < ADAM_MAX_ITEMS; ++i) aa.it[i] = AdamItem{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0x7FFFFFFF};
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, aa);
+    if (int rc = check_launch("adam_multi")) return rc;
+  }
+  return ADVHIP_OK;
+}
+
 extern "C" int advhip_amp_combine_fwd_f32(const float* z, const float* bias, const float* mag, int64_t mag_stride, const float* wm, const float* bm,
                                           float ratio, float* y, int32_t O, int64_t rows, int32_t T, void* stream) {
   ADVHIP_REQUIRE(z && bias && mag && wm && bm && y && O > 0 && rows > 0 && T > 0 && mag_stride > 0, "amp_combine_fwd: bad arguments");

@@ -948,6 +948,33 @@ class _DWConvT(torch.autograd.Function):
         return dv, per_head[:, :k].reshape(ctx.wshape), per_head[:, k].contiguous()
 
 
+class _TokenTaps(torch.autograd.Function):
+    """z = Wt @ Xr^T for Wt (k*O, C) -- the k tap matrices of the 2048 -> 64 token conv stacked -- and Xr (N, C) the scorer's
+    input rows AS STORED (positions x channels, row pitch C + 1: the magnitude column rides along): both operands are
+    contraction-contiguous, i.e. advhip_gemm_nt_f32 reads them in place (MGFNFeatureAmplifier._tokens_by_taps,
+    /root/reference/src/models/mgfn/modeling_mgfn.py:81-93).  Backward: dWt = dZ @ Xr (advhip_bgemm_f32 on the same rows);
+    the input carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, wt, xr):
+        ctx.save_for_backward(xr)
+        return ops.gemm_nt(wt, xr)
+
+    @staticmethod
+    def backward(ctx, dz):
+        (xr,) = ctx.saved_tensors
+        return ops.bgemm(dz.contiguous(), xr)[0], None
+
+
+def token_taps_ok(wt: torch.Tensor, xr: torch.Tensor) -> bool:
+    return (_on_current_device(xr) and xr.dtype == torch.float32 and wt.dtype == torch.float32 and xr.dim() == 2 and xr.stride(1) == 1
+            and wt.shape[1] % 16 == 0 and wt.shape[1] == xr.shape[1] and not xr.requires_grad)
+
+
+def token_taps(wt: torch.Tensor, xr: torch.Tensor) -> torch.Tensor:
+    return _TokenTaps.apply(wt.contiguous(), xr)
+
+
 class _AmpCombine(torch.autograd.Function):
     """tokens = sum_j shift_j(z[j]) + bias + ratio * Conv1d_k3(magnitude): what follows the tap GEMM in MGFNFeatureAmplifier
     (modeling_mgfn.py:81-93) as one launch forward and one backward (include/advhip.h: advhip_amp_combine_*_f32)."""

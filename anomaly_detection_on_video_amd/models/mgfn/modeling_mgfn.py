@@ -170,16 +170,18 @@ class MGFNFeatureAmplifier(nn.Module):
 
     def forward(self, x):
         bs, ncrops, t, c = x.shape
+        rows = x.reshape(bs * ncrops * t, c)               # the input as stored: (positions, channels + magnitude)
         x = x.reshape(bs * ncrops, t, c).permute(2, 0, 1)  # (C+1, B, T) view
-        if torch.is_grad_enabled() and self.to_tokens.weight.requires_grad:
-            tokens, whole = self._tokens_by_taps(x, bs * ncrops, t)
+        if (torch.is_grad_enabled() and self.to_tokens.weight.requires_grad) or mgfn_ops.fused_ok(x):
+            # (with autograd, and on the GPU without it too: no unfolded input, no torch GEMM -- eval's 1 -> 64 magnitude conv included)
+            tokens, whole = self._tokens_by_taps(x, bs * ncrops, t, rows)
             if whole:  # (the magnitude conv, the scale and the sum went into the launch that finishes the token conv)
                 return tokens
         else:
             tokens = _conv_k(self.to_tokens, x[: self.channels])
         return tokens + self.mag_ratio * _conv_k(self.to_mag, x[self.channels :])
 
-    def _tokens_by_taps(self, x, b, t):
+    def _tokens_by_taps(self, x, b, t, rows=None):
         """The 2048 -> 64 token conv with autograd, without unfolding its input: a k-tap conv is linear in its taps,
         conv_k(x)[o, t] = sum_j (W_j x)[o, t + j - k/2], so ONE GEMM of the stacked tap matrices (k*64 x 2048) with the input AS
         STORED (positions x channels, read through its strides: no transposed / padded / tap-stacked copy, 84 + 252 MB at the
@@ -187,8 +189,13 @@ class MGFNFeatureAmplifier(nn.Module):
         finishes the conv.  Backward (autograd): dW = dZ X, again on the input as stored; no input gradient."""
         conv = self.to_tokens
         o, c, k = conv.weight.shape
-        xv = x[:c].reshape(c, b * t)                                      # (C, B*T) view of the (B*T, C+1) rows: strides (1, C+1)
-        z = torch.matmul(conv.weight.permute(2, 0, 1).reshape(k * o, c), xv).view(k, o, b, t)
+        wt = conv.weight.permute(2, 0, 1).reshape(k * o, c)              # the k tap matrices, stacked
+        xr = rows[:, :c] if rows is not None else None                    # (B*T, C) rows of pitch C + 1, read in place
+        if xr is not None and mgfn_ops.token_taps_ok(wt, xr):
+            z = mgfn_ops.token_taps(wt, xr).view(k, o, b, t)              # advhip_gemm_nt_f32 forward, advhip_bgemm_f32 weight gradient
+        else:
+            xv = x[:c].reshape(c, b * t)                                  # (C, B*T) view of the (B*T, C+1) rows: strides (1, C+1)
+            z = torch.matmul(wt, xv).view(k, o, b, t)
         mag = x[c:]
         if k == 3 and mgfn_ops.amp_combine_ok(z, conv, self.to_mag, mag):
             # the shifted add, the bias AND mag_ratio * to_mag(magnitude): one HIP launch forward, one backward -> (tokens, True)

@@ -242,6 +242,7 @@ def main():
     stream.drain()
     barrier()
     elapsed = time.perf_counter() - t0
+    videos_timed = stream.videos_scored - videos_before  # (the counter keeps running through the sustained / PCIe legs below)
     backbone.forward = orig_forward
     rank_elapsed = [elapsed]
     backend_observed, world_observed = "none (single process)", 1
@@ -453,7 +454,7 @@ def main():
                 if world == 1 else
                 f"I3D-RGB extraction sharded over {world}xMI355X, RCCL all-gather of 2048-d features, synthetic UCF-Crime-shape stream -> MGFN MIL score",
                 "clip": "3x16x224x224 fp32", "local_batch": args.batch, "global_batch": args.batch * world,
-                "clips_per_video": 32, "ncrops": 10, "videos_scored_rank0": stream.videos_scored - videos_before,
+                "clips_per_video": 32, "ncrops": 10, "videos_scored_rank0": videos_timed,
                 "weights": "deterministic synthetic (no network)", "parallelism": f"dp{world}",
                 "backend": backend_observed, "world_size_observed": world_observed,  # what torch.distributed reports, not what was asked for
                 "rank_clips_per_s_min": round(args.batch * args.steps / max(rank_elapsed), 2),

@@ -60,6 +60,12 @@ extern "C" {
  * for (kt,1,1) stride-1 "same" convs: the temporal taps of a tile re-read the same activation rows from L1/L2 instead of
  * three far-apart tiles fetching them from HBM.  Unsplit; T even. */
 #define ADVHIP_ALGO_TSPAN_128x64 192
+/* + tile id (ADVHIP_ALGO_IGEMM_128x64 or _64x64) + 8 * (W - 1): the PERSISTENT form of the LDS-DMA kernel for unsplit 1x1x1
+ * stride-1 convs on 16-byte aligned rows (the `conv3` + residual launches, src/i3d.py:85-89, 108-121): W workgroups per compute
+ * unit (1..4) that stay for the whole launch; each walks a contiguous share of the output tiles with the LDS-DMA ring running
+ * across tile boundaries (3 stages) and an epilogue staging area of its own.  Same k order and accumulation chain as the other
+ * families: bit-identical results.  Never chosen by ADVHIP_ALGO_AUTO. */
+#define ADVHIP_ALGO_PERSIST_BASE 224
 
 typedef struct advhip_conv3d_desc {
   int32_t B, Cin, T, H, W;    /* input  (B, Cin, T, H, W) */
@@ -300,10 +306,11 @@ typedef struct advhip_gemm_desc {
 } advhip_gemm_desc;
 int advhip_bgemm_f32(const advhip_gemm_desc* d, const float* A, const float* B, float* C, void* stream);
 
-/* C[s][m][n] = sum over K slice s of A[m][k] * B[n][k]: both operands k-contiguous with row pitches lda / ldb (elements,
- * multiples of 4; K a multiple of 16; 16-byte aligned bases).  The weight gradient dW[o][c] = sum_n dY[o][n] X[c][n] of
- * the MGFN scorer's GEMM-shaped layers, whose activations are stored (channel, position): no transposed copies.  LDS-DMA
- * row copies, fp32 MFMA.  splits > 1 cuts K into slices written to C + s * slab_stride (the caller sums them). */
+/* C[s][m][n] = sum over K slice s of A[m][k] * B[n][k]: both operands k-contiguous with row pitches lda / ldb (elements, any
+ * value >= K: a 16-byte LDS-DMA piece takes any 4-byte aligned address on gfx950; K a multiple of 16; 4-byte aligned bases).
+ * The weight gradient dW[o][c] = sum_n dY[o][n] X[c][n] of the MGFN scorer's GEMM-shaped layers, whose activations are stored
+ * (channel, position): no transposed copies; and the token conv's tap products on the scorer's input rows as stored (2 049-float
+ * pitch, modeling_mgfn.py:81-93).  LDS-DMA row copies, fp32 MFMA.  splits > 1 cuts K into slices written to C + s * slab_stride (the caller sums them). */
 int advhip_gemm_nt_f32(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb,
                        int64_t ldc, int32_t splits, int64_t slab_stride, void* stream);
 
@@ -433,6 +440,23 @@ typedef struct advhip_colsum_item {
   int32_t period;
 } advhip_colsum_item;
 int advhip_colsum_group_f32(const advhip_colsum_item* items, int32_t n_items, void* stream);
+
+/* torch.optim.Adam's update (L2 weight decay added to the gradient, no amsgrad; /root/reference/src/runner.py:53-59) for many fp32
+ * tensors in one launch per 80 of them (`items`: a HOST array, carried in the kernel arguments -- graph-capturable as is):
+ *   g' = g + wd p;  m += (1 - b1)(g' - m);  v = b2 v + (1 - b2) g'^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+ * (fp32 arithmetic; 1 - beta and lr / (1 - beta^t) formed in double and rounded once, as torch's Python code does)
+ * with t = *step: a device-side fp32 counter (torch's capturable Adam keeps one per parameter) that the caller has already
+ * incremented for this step. */
+typedef struct advhip_adam_item {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  const float* step;
+  int64_t n;
+} advhip_adam_item;
+int advhip_adam_multi_f32(const advhip_adam_item* items, int32_t n_items, double lr, double beta1, double beta2, double eps,
+                          double weight_decay, void* stream);
 
 /* The operand of a k = 3, padding 1 Conv1d's weight gradient (autograd of nn.Conv1d, modeling_mgfn.py:101,155):
  * u[(c*3 + j), r, t] = x[c, r, t + j - 1] (zero outside [0, T)), x (C, rows, T) -> u (3C, rows, T); dW = dY . u^T by

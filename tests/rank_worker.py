@@ -19,7 +19,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-CLIPS_PER_VIDEO, NCROPS, LOCAL_BATCH, STEPS = 3, 2, 2, 3  # W videos of 3 clips x 2 crops in 3 global batches of 2W crop-clips
+# "small": W videos of 3 clips x 2 crops in 3 global batches of 2W crop-clips of 16 x 48 x 48 (ordering / ownership logic);
+# "bench": the benchmarked shape -- 32 crop-clips of 16 x 224 x 224 per rank and step (the tuned B = 32 plan, its split-K
+# launches on per-stream counter blocks, the stream's lanes), 2 steps, videos of 4 clips x 10 crops so that some complete
+CONFIGS = {
+    "small": dict(clips_per_video=3, ncrops=2, local_batch=2, steps=3, hw=48),
+    "bench": dict(clips_per_video=4, ncrops=10, local_batch=32, steps=2, hw=224),
+}
+CLIPS_PER_VIDEO, NCROPS, LOCAL_BATCH, STEPS = 3, 2, 2, 3  # (the "small" configuration, by its old names)
 
 
 def models(dev):
@@ -34,10 +41,17 @@ def models(dev):
     return bb.eval().to(dev), sc.eval().to(dev)
 
 
-def clips(world):
-    from anomaly_detection_on_video_amd.weights import synth_tensor
+def clips(world, shape="small"):
+    from anomaly_detection_on_video_amd.weights import synth_input, synth_tensor
 
-    return synth_tensor("dist.gpu.x", (STEPS * LOCAL_BATCH * world, 3, 16, 48, 48), scale=2.0)
+    cfg = CONFIGS[shape]
+    n = cfg["steps"] * cfg["local_batch"] * world
+    if shape == "small":
+        return synth_tensor("dist.gpu.x", (n, 3, 16, cfg["hw"], cfg["hw"]), scale=2.0)
+    # four distinct full-size clips (hashing 100+ of them takes minutes), dealt so that neighbouring rows, ranks and steps differ
+    base = torch.cat([synth_input((2, 3, 16, cfg["hw"], cfg["hw"]), seed) for seed in (0, 1)])
+    idx = torch.tensor([(i * 7 + i // cfg["local_batch"]) % 4 for i in range(n)])
+    return base[idx]
 
 
 def main():
@@ -45,7 +59,10 @@ def main():
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--share-gpu", action="store_true")
     ap.add_argument("--out", required=True)
+    ap.add_argument("--shape", default="small", choices=sorted(CONFIGS))
     args = ap.parse_args()
+    cfg = CONFIGS[args.shape]
+    lb, steps = cfg["local_batch"], cfg["steps"]
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from anomaly_detection_on_video_amd import dist as adist
     from anomaly_detection_on_video_amd.pipeline import ExtractScoreStream
@@ -59,18 +76,18 @@ def main():
         os.environ["LOCAL_RANK"] = str(local_rank)
     adist.init_process_group(args.backend)
     bb, sc = models(dev)
-    stream = ExtractScoreStream(bb, sc, clips_per_video=CLIPS_PER_VIDEO, ncrops=NCROPS, local_batch=LOCAL_BATCH, world=world, rank=rank)
-    x = clips(world)
-    gb = LOCAL_BATCH * world
+    stream = ExtractScoreStream(bb, sc, clips_per_video=cfg["clips_per_video"], ncrops=cfg["ncrops"], local_batch=lb, world=world, rank=rank)
+    x = clips(world, args.shape)
+    gb = lb * world
     handles = []
-    for g in range(STEPS):
-        lo = g * gb + rank * LOCAL_BATCH
-        handles.append(stream.step_async(x[lo : lo + LOCAL_BATCH].to(dev)))
+    for g in range(steps):
+        lo = g * gb + rank * lb
+        handles.append(stream.step_async(x[lo : lo + lb].to(dev)))
     stream.drain()
     torch.cuda.synchronize()
     res = [h.result() for h in handles]
     torch.save({"gathered": [g.cpu() for g, _s in res], "scored": [(v, s.cpu()) for _g, sl in res for v, s in sl],
-                "backend": torch.distributed.get_backend(), "world": torch.distributed.get_world_size(), "device": str(dev)},
+                "backend": torch.distributed.get_backend(), "world": torch.distributed.get_world_size(), "device": str(dev), "lanes": stream.lanes},
                os.path.join(args.out, f"r{rank}.pt"))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

@@ -374,3 +374,50 @@ def test_graphed_training_steps_equal_eager_steps_bit_for_bit():
     m_g.injected_keep = (ones, ones)
     # (the captured graph holds the ORIGINAL keep tensors: pinned masks are part of the capture)
     assert torch.isfinite(graphed(batches[0], al, nl)) and graphed.replays == 4
+
+
+def test_hip_adam_tracks_torch_adam_and_shares_its_state_layout():
+    """optim.HipAdam (one launch per 80 tensors) against torch.optim.Adam, the reference's optimizer (/root/reference/src/runner.py:53-59):
+    same update after several steps on tensors of ragged sizes (vector body + scalar tails, > 80 tensors = two launches), a
+    parameter without a gradient keeps its step count, and state_dict() round-trips between the two classes."""
+    from anomaly_detection_on_video_amd.optim import HipAdam
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    shapes = [(64, 2048, 3), (64,), (1024, 1024, 1), (7,), (1, 33, 5), (4099,), (3, 3)] + [(5 + i,) for i in range(90)]
+    ref_p = [torch.randn(s, generator=g).to(dev).requires_grad_() for s in shapes]
+    hip_p = [p.detach().clone().requires_grad_() for p in ref_p]
+    ref = torch.optim.Adam(ref_p, lr=1e-3, weight_decay=5e-4)
+    hip = HipAdam(hip_p, lr=1e-3, weight_decay=5e-4)
+    for step in range(4):
+        for i, (a, b) in enumerate(zip(ref_p, hip_p)):
+            if step == 2 and i == 3:  # no gradient for this one in this step
+                a.grad = b.grad = None
+                continue
+            gr = torch.randn(a.shape, generator=g).to(dev) * (1.0 + i % 3)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        ref.step()
+        hip.step()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(ref_p, hip_p)):
+        assert rel_err(b.detach().cpu(), a.detach().cpu()) < 2e-6, i
+        sa, sb = ref.state[a], hip.state[b]
+        assert float(sb["step"]) == float(sa["step"]) == (3.0 if i == 3 else 4.0)
+        assert rel_err(sb["exp_avg"].cpu(), sa["exp_avg"].cpu()) < 2e-6 and rel_err(sb["exp_avg_sq"].cpu(), sa["exp_avg_sq"].cpu()) < 2e-6
+    # state interchange: torch's state into HipAdam (what a resumed reference checkpoint does) and back
+    hip2_p = [p.detach().clone().requires_grad_() for p in ref_p]
+    hip2 = HipAdam(hip2_p, lr=1e-3, weight_decay=5e-4)
+    hip2.load_state_dict(ref.state_dict())
+    ref2_p = [p.detach().clone().requires_grad_() for p in ref_p]
+    ref2 = torch.optim.Adam(ref2_p, lr=1e-3, weight_decay=5e-4)
+    ref2.load_state_dict(hip.state_dict())
+    for a, b, c in zip(ref_p, hip2_p, ref2_p):
+        gr = torch.randn(a.shape, generator=g).to(dev)
+        a.grad, b.grad, c.grad = gr.clone(), gr.clone(), gr.clone()
+    ref.step()
+    hip2.step()
+    ref2.step()
+    torch.cuda.synchronize()
+    for i, (a, b, c) in enumerate(zip(ref_p, hip2_p, ref2_p)):
+        assert rel_err(b.detach().cpu(), a.detach().cpu()) < 2e-6, i
+        assert rel_err(c.detach().cpu(), a.detach().cpu()) < 3e-6, i

@@ -27,9 +27,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_ranks(world, backend, share_gpu, out_dir):
+def _run_ranks(world, backend, share_gpu, out_dir, shape="small"):
     argv = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-            "--master-port", str(_free_port()), os.path.join(REPO, "tests", "rank_worker.py"), "--backend", backend, "--out", out_dir]
+            "--master-port", str(_free_port()), os.path.join(REPO, "tests", "rank_worker.py"), "--backend", backend, "--out", out_dir, "--shape", shape]
     if share_gpu:
         argv.append("--share-gpu")
     rep = launch_fresh(argv, env={"HSA_ENABLE_IPC_MODE_LEGACY": "0"}, unset=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"), timeout=900)
@@ -37,13 +37,14 @@ def _run_ranks(world, backend, share_gpu, out_dir):
     return [torch.load(os.path.join(out_dir, f"r{r}.pt")) for r in range(world)]
 
 
-def _single_process(world):
+def _single_process(world, shape="small"):
     from anomaly_detection_on_video_amd.pipeline import ExtractScoreStream
 
+    cfg = rank_worker.CONFIGS[shape]
     bb, sc = rank_worker.models("cuda:0")
-    x = rank_worker.clips(world)
-    lb = rank_worker.LOCAL_BATCH
-    single = ExtractScoreStream(bb, sc, clips_per_video=rank_worker.CLIPS_PER_VIDEO, ncrops=rank_worker.NCROPS, local_batch=lb, world=1, rank=0)
+    x = rank_worker.clips(world, shape)
+    lb = cfg["local_batch"]
+    single = ExtractScoreStream(bb, sc, clips_per_video=cfg["clips_per_video"], ncrops=cfg["ncrops"], local_batch=lb, world=1, rank=0)
     rows, scores = [], {}
     for i in range(0, x.shape[0], lb):  # the same blocks of LOCAL_BATCH crop-clips per launch, stream order
         g, sl = single.step(x[i : i + lb].to("cuda:0"))
@@ -53,14 +54,15 @@ def _single_process(world):
     return torch.cat(rows), scores
 
 
-def _check(ranks, world, backend):
-    rows, scores = _single_process(world)
-    gb = rank_worker.LOCAL_BATCH * world
-    assert len(scores) == world  # W videos in the stream
+def _check(ranks, world, backend, shape="small"):
+    cfg = rank_worker.CONFIGS[shape]
+    rows, scores = _single_process(world, shape)
+    gb = cfg["local_batch"] * world
+    assert len(scores) == cfg["steps"] * gb // (cfg["clips_per_video"] * cfg["ncrops"])  # the videos that complete in the stream
     seen = []
     for r, rec in enumerate(ranks):
         assert rec["backend"] == backend and rec["world"] == world
-        for g in range(rank_worker.STEPS):
+        for g in range(cfg["steps"]):
             assert torch.equal(rec["gathered"][g], rows[gb * g : gb * (g + 1)]), (r, g)  # rank-major all-gather == stream order, on every rank
         assert [v for v, _ in rec["scored"]] == [v for v in sorted(scores) if v % world == r]  # video v -> rank v % W
         for v, s in rec["scored"]:
@@ -81,3 +83,45 @@ def test_one_rank_per_gpu_over_rccl_equals_one_process(tmp_path):
     ranks = _run_ranks(world, "nccl", False, str(tmp_path))
     assert sorted(rec["device"] for rec in ranks) == sorted(f"cuda:{r}" for r in range(world))
     _check(ranks, world, "nccl")
+
+
+def test_two_ranks_at_the_benchmarked_shape_equal_one_process(tmp_path):
+    """Two rank processes at once on the tuned B = 32 / 16 x 224 x 224 plan (what `bench.py --gpus N` runs per rank: split-K launches
+    on per-stream counter blocks, three lanes per rank), sharing cuda:0 over gloo: same bits as one process."""
+    ranks = _run_ranks(2, "gloo", True, str(tmp_path), shape="bench")
+    assert all(rec["lanes"] == 3 for rec in ranks)
+    _check(ranks, 2, "gloo", shape="bench")
+
+
+def _bench_two_ranks(extra_env):
+    import json
+
+    env = {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    env.update(extra_env)
+    rep = launch_fresh([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--sustain-s", "0"],
+                       env=env, unset=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR") + (() if extra_env else ("ADV_BENCH_SHARE_GPU",)), timeout=900)
+    assert rep["rc"] == 0, rep["stderr"][-4000:] + rep["stdout"][-2000:]
+    lines = [ln for ln in rep["stdout"].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, rep["stdout"][-2000:]  # exactly ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak" and out["unit"] == "clips/s"
+    cfg = out["config"]
+    assert cfg["world_size_observed"] == 2 and cfg["global_batch"] == 64 and cfg["parallelism"] == "dp2"
+    assert cfg["rank_clips_per_s_min"] > 0 and cfg["rank_clips_per_s_max"] >= cfg["rank_clips_per_s_min"]
+    assert out["value"] > 0 and abs(out["value"] - 2 * cfg["rank_clips_per_s_min"]) < 1e-6 * out["value"] + 0.02  # whole-job rate = all ranks' clips / the slowest rank's time
+    assert 0 < out["roofline"]["frac"] < 1 and out["roofline"]["unit"] == "TFLOP/s"
+    assert "cpu_baseline" not in out and "mgfn_train_step" not in out  # rank 0 at N = 1 only
+    return out
+
+
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` the way the driver starts it (no torchrun around it), as the one-GPU rehearsal: bench.py is
+    its own launcher, both ranks run the real B = 32 stream on cuda:0, the gather goes over gloo, rank 0 prints the one line."""
+    out = _bench_two_ranks({"ADV_BENCH_SHARE_GPU": "1"})
+    assert out["config"]["backend"] == "gloo" and "REHEARSAL" in out["data"]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs: one rank per GPU over RCCL")
+def test_bench_two_ranks_over_rccl():
+    out = _bench_two_ranks({})
+    assert out["config"]["backend"] == "nccl" and out["data"] == "synthetic"
