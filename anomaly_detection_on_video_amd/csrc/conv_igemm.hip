@@ -1430,52 +1430,31 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
 }
 
 // ================================================================================================
-// Persistent, wave-specialised form of the LDS-DMA kernel for unsplit 1x1x1 stride-1 convs on 16-byte aligned rows
-// (ConvArgs::a16): the `conv3` (+ residual) launches of every Bottleneck (src/i3d.py:85-89, 108-121) and the k = 1 `conv1`s.
-// Their K is 64-512, i.e. 4-32 k-tiles per output tile: in the one-tile-per-workgroup kernel above a tile's life is index
-// arithmetic, ring fill, a short MFMA run and then the epilogue's residual round trip, every `buffer_load ... lds` a wave issues
-// holds up that wave's own MFMA stream, and the kernel lives on eight resident waves per SIMD covering for each other
-// (profiles/r03_final_*: 40-58 % MFMA-busy on these launches against 82 % for the stem).  Here:
+// Persistent, wave-specialised kernel for unsplit 1x1x1 stride-1 convs on 16-byte aligned rows (ConvArgs::a16): the `conv3`
+// (+ residual) launches of every Bottleneck (src/i3d.py:85-89, 108-121) and the k = 1 `conv1`s.  OPT-IN (ADVHIP_ALGO_PERSIST_BASE):
+// measured slower than the tuned one-tile-per-workgroup kernels on every B = 32 shape (profiles/r04_persist_kernel_study.md has the
+// five forms that were built, their timings and in-kernel cycle stamps, and why); kept as the tested end point of that study.
 //   * a launch is W x (compute units) workgroups of EIGHT waves that stay; each walks a contiguous share of its XCD's part of the
 //     output tiles (n fastest: the n-tiles of an m-tile re-read the same activation rows from the XCD's L2);
 //   * waves 0-3 only feed the matrix pipe: barrier, fragment reads, MFMAs.  At the end of a tile they apply scale / shift and
 //     drop the tile into an LDS staging area (8 ds_write_b128 per lane), then go on with the next tile;
-//   * waves 4-7 are the loaders and the epilogue.  Every k-tile interval they issue the LDS-DMA loads of the operand ring --
-//     which runs ACROSS tile boundaries, NS - 1 k-tiles ahead, so no tile after a workgroup's first waits for a ring fill -- and
-//     wait (an exact count) for the NEXT k-tile to have landed before they arrive at the barrier that releases it.  One
-//     interval after a tile was staged they pick it up into registers and issue its residual loads; two intervals later
-//     (the loads have landed beside the other waves' MFMAs) they add, apply the activation and store whole 16-byte pieces of
+//   * waves 4-7 are the loaders and the epilogue.  Loader wave w fetches the k-tiles q = w (mod 4) -- whole k-tiles, plain 16-byte
+//     buffer loads into registers, four k-tiles ahead and ACROSS tile boundaries, so no tile after a workgroup's first waits for a
+//     fill -- and writes each to the two-stage LDS ring one interval before it is multiplied.  One interval after a tile was
+//     staged they issue its residual loads; two intervals later they add, apply the activation and store whole 16-byte pieces of
 //     NCDHW rows;
-//   * the ONE barrier per k-tile that the ring needs anyway is all the synchronisation there is: both roles execute the same
-//     number of barriers; a staged tile is written after the barrier of its last k-tile and read after the next one.
+//   * the ONE barrier per k-tile is all the synchronisation there is: both roles execute the same number of barriers; a staged
+//     tile is written after the barrier of its last k-tile and read in the third interval of its successor (nk >= 4).
 // Same operand layout, k order and accumulation chain as conv3d_igemm_dma_kernel (unsplit): bit-identical results.
-template <int N>
-__device__ __forceinline__ void wait_vmcnt_switch(int n) {  // s_waitcnt vmcnt(min(n, N)) for a wave-uniform n (the immediate needs a constant)
-  static_assert(N <= 40, "cases");
-  const int c = n < N ? (n < 0 ? 0 : n) : N;
-#define ADVHIP_VMCNT_CASE(I) \
-  case I: asm volatile("s_waitcnt vmcnt(" #I ")" ::: "memory"); break;
-  switch (c) {
-    ADVHIP_VMCNT_CASE(0) ADVHIP_VMCNT_CASE(1) ADVHIP_VMCNT_CASE(2) ADVHIP_VMCNT_CASE(3) ADVHIP_VMCNT_CASE(4) ADVHIP_VMCNT_CASE(5) ADVHIP_VMCNT_CASE(6)
-    ADVHIP_VMCNT_CASE(7) ADVHIP_VMCNT_CASE(8) ADVHIP_VMCNT_CASE(9) ADVHIP_VMCNT_CASE(10) ADVHIP_VMCNT_CASE(11) ADVHIP_VMCNT_CASE(12) ADVHIP_VMCNT_CASE(13)
-    ADVHIP_VMCNT_CASE(14) ADVHIP_VMCNT_CASE(15) ADVHIP_VMCNT_CASE(16) ADVHIP_VMCNT_CASE(17) ADVHIP_VMCNT_CASE(18) ADVHIP_VMCNT_CASE(19) ADVHIP_VMCNT_CASE(20)
-    ADVHIP_VMCNT_CASE(21) ADVHIP_VMCNT_CASE(22) ADVHIP_VMCNT_CASE(23) ADVHIP_VMCNT_CASE(24) ADVHIP_VMCNT_CASE(25) ADVHIP_VMCNT_CASE(26) ADVHIP_VMCNT_CASE(27)
-    ADVHIP_VMCNT_CASE(28) ADVHIP_VMCNT_CASE(29) ADVHIP_VMCNT_CASE(30) ADVHIP_VMCNT_CASE(31) ADVHIP_VMCNT_CASE(32) ADVHIP_VMCNT_CASE(33) ADVHIP_VMCNT_CASE(34)
-    ADVHIP_VMCNT_CASE(35) ADVHIP_VMCNT_CASE(36) ADVHIP_VMCNT_CASE(37) ADVHIP_VMCNT_CASE(38) ADVHIP_VMCNT_CASE(39) ADVHIP_VMCNT_CASE(40)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-#undef ADVHIP_VMCNT_CASE
-}
-
 // (registers: two 8-wave workgroups per CU for the 128-row tile = 4 waves per SIMD = 128 VGPRs; three for the 64-row one)
-template <int BM, int BN, int NS, bool DBG = false>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BM == 128 ? 4 : 6, 8)))
+template <int BM, int BN, int NS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void conv1x1_persist_kernel(const ConvArgs a) {
   constexpr int BK = 16;
   using Cfg = IgemmCfg<BM, BN, BK>;
   using D = DmaCfg<BM, BN, BK>;
   constexpr int FM = Cfg::FM, FN = Cfg::FN, LB = D::LB, KS = BK / 4;
-  static_assert(NS == 2, "LDS ring depth (the depth of the prefetch is the loader waves' register sets)");
+  static_assert(NS == 2, "LDS ring depth (the depth of the prefetch is the loader waves' registers)");
   static_assert(BN == 64 && (BM == 128 || BM == 64), "tile");
   constexpr unsigned OOB = 0xFFFFFF00u;
   constexpr int RING = NS * D::STAGE;
@@ -1561,12 +1540,8 @@ void conv1x1_persist_kernel(const ConvArgs a) {
     };
     load_scale(t0);
     int stage = 0, kt = 0, tile = t0;
-    unsigned long long dbg_bar = 0, dbg_t0 = 0, dbg_start = 0;
-    if constexpr (DBG) dbg_start = __builtin_amdgcn_s_memtime();
     for (int q = 0; q < total; ++q) {
-      if constexpr (DBG) dbg_t0 = __builtin_amdgcn_s_memtime();
       asm volatile("s_barrier" ::: "memory");  // k-tile q is in LDS (the loaders waited for it before they arrived)
-      if constexpr (DBG) dbg_bar += __builtin_amdgcn_s_memtime() - dbg_t0;
       compute(stage);
       stage = stage == NS - 1 ? 0 : stage + 1;
       if (++kt == nk) {
@@ -1605,33 +1580,27 @@ void conv1x1_persist_kernel(const ConvArgs a) {
       }
     }
     asm volatile("s_barrier" ::: "memory");  // the last tile is staged
-    if constexpr (DBG) {
-      if (tid == 0) {
-        unsigned long long* d = reinterpret_cast<unsigned long long*>(a.y2) + (size_t)blockIdx.x * 8;
-        d[0] = __builtin_amdgcn_s_memtime() - dbg_start;
-        d[1] = dbg_bar;
-        d[2] = (unsigned long long)total;
-      }
-    }
     return;
   }
 
   // ------------------------------------------------------------------ loader + epilogue waves
-  // Operands go global -> registers -> LDS here (plain 16-byte buffer loads, PD k-tiles of them in flight per wave, then
-  // ds_write_b128 one interval before the k-tile is multiplied): an LDS-DMA instruction holds its issuing wave for ~500 cycles with
-  // one wave per SIMD issuing (in-kernel stamps, tools/persist_stamps.py: four loader waves moved 6 B/clk per CU with LDS-DMA,
-  // which made THEM the bottleneck); ordinary loads issue in a few cycles each and these waves have the registers to spare.  Every
-  // vector-memory operation of these waves is visible to hipcc, which counts its waits exactly (no LDS-DMA in the kernel: none of
-  // its conservative vmcnt(0) rules apply).
-  constexpr int PD = 3;  // k-tiles of operand loads in flight per loader wave (beyond the one being written to LDS)
+  // Operands go global -> registers -> LDS here: plain 16-byte buffer loads, ds_write_b128 one interval before the k-tile is
+  // multiplied.  LDS-DMA does not serve a loader: with four to eight waves issuing, `buffer_load ... lds` moves ~1 KB per ~480 cycles
+  // and SIMD whatever the ring depth or issue priority (in-kernel stamps, tools/persist_stamps.py: 8.5 B/clk per CU, the loaders
+  // became the bottleneck at ~2 000 cycles per k-tile against 1 200 for the MFMA waves); ordinary loads have no such limit and these
+  // waves have the registers.  Loader wave w takes the k-tiles q = w (mod 4), a WHOLE k-tile each (12 loads per lane), so that
+  // every wave runs the same code on one register set and up to four k-tiles are in flight per workgroup: the loads of k-tile
+  // q + 4 go out in the interval in which k-tile q was written to LDS, and are written three intervals later.  Every
+  // vector-memory operation of these waves is visible to hipcc, which counts its waits itself (no LDS-DMA left in the kernel).
   using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+  constexpr int NA = BK * BM / 256, NB = BK * BN / 256;  // 16-byte loads per lane for a whole k-tile of A / B (8 or 4, and 4)
   const int lw = wave - 4;
   const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
   const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
   const unsigned wvoff = (unsigned)((lane / LPRB) * a.Cout + (lane % LPRB) * 4) * 4u;
   const int a_lane4 = (lane % (BM / 4)) * 4, a_lrow = lane / (BM / 4);
-  // the tile operands are being fetched for (runs PD k-tiles ahead of the one being multiplied)
-  int p_tile = t0, p_kt = 0, p_n0 = 0;
+  // the k-tile this wave fetches next: k-tile p_kt of tile p_tile (global index p_q = lw, lw + 4, ...)
+  int p_tile = t0, p_kt = lw, p_q = lw, p_n0 = 0;
   unsigned p_vbase = OOB;
   auto set_prefetch_tile = [&](int L) __attribute__((always_inline)) {
     const int tm = (int)a.dTilesN.div((unsigned)L), tn = L - tm * a.tiles_n;
@@ -1643,40 +1612,28 @@ void conv1x1_persist_kernel(const ConvArgs a) {
       p_vbase = (unsigned)(b4 * a.x_bstride + (m4 - b4 * a.MP) + a_lrow * a.THW) * 4u;
     }
   };
-  set_prefetch_tile(t0);
-  u32x4 ra[PD][LA16], rb[PD][LB];
-  auto load_next = [&](auto d_c) __attribute__((always_inline)) {  // k-tile p_kt of tile p_tile into register set d, then advance
-    constexpr int d = decltype(d_c)::value;
+  set_prefetch_tile(t0);  // (nk >= 4 > lw: the first k-tile of every loader wave lies in the first tile)
+  u32x4 ra[NA], rb[NB];
+  auto load_ktile = [&]() __attribute__((always_inline)) {  // k-tile (p_tile, p_kt) -> registers, then advance by four k-tiles
     const int k0 = p_kt * BK;
 #pragma unroll
-    for (int q = 0; q < LA16; ++q) {
-      const int g = lw * LA16 + q;
-      ra[d][q] = __builtin_amdgcn_raw_buffer_load_b128(rx, p_vbase, (k0 + g * RPI16) * a.THW * 4, 0);
-    }
+    for (int g = 0; g < NA; ++g) ra[g] = __builtin_amdgcn_raw_buffer_load_b128(rx, p_vbase, (k0 + g * RPI16) * a.THW * 4, 0);
 #pragma unroll
-    for (int q = 0; q < LB; ++q) {
-      const int row0 = (lw * LB + q) * RPW;
-      rb[d][q] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, ((k0 + row0) * a.Cout + p_n0) * 4, 0);
-    }
-    if (++p_kt == nk) {
-      p_kt = 0;
+    for (int g = 0; g < NB; ++g) rb[g] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, ((k0 + g * RPW) * a.Cout + p_n0) * 4, 0);
+    p_q += 4;
+    p_kt += 4;
+    if (p_kt >= nk) {
+      p_kt -= nk;
       if (++p_tile < t1) set_prefetch_tile(p_tile);
     }
   };
-  auto write_stage = [&](auto d_c, int stage) __attribute__((always_inline)) {  // register set d -> ring stage `stage` (the image the LDS-DMA form writes: linear in the lane)
-    constexpr int d = decltype(d_c)::value;
+  auto write_ktile = [&](int stage) __attribute__((always_inline)) {  // registers -> ring stage (the image the LDS-DMA form writes: linear in the lane)
     float* As = smem + stage * D::STAGE;
     float* Bs = As + BK * BM;
 #pragma unroll
-    for (int q = 0; q < LA16; ++q) {
-      const int g = lw * LA16 + q;
-      *reinterpret_cast<u32x4*>(As + g * RPI16 * BM + lane * 4) = ra[d][q];
-    }
+    for (int g = 0; g < NA; ++g) *reinterpret_cast<u32x4*>(As + g * RPI16 * BM + lane * 4) = ra[g];
 #pragma unroll
-    for (int q = 0; q < LB; ++q) {
-      const int row0 = (lw * LB + q) * RPW;
-      *reinterpret_cast<u32x4*>(Bs + row0 * BN + lane * 4) = rb[d][q];
-    }
+    for (int g = 0; g < NB; ++g) *reinterpret_cast<u32x4*>(Bs + g * RPW * BN + lane * 4) = rb[g];
   };
 
   const int e = tid - 256;                       // 0..255
@@ -1715,7 +1672,7 @@ void conv1x1_persist_kernel(const ConvArgs a) {
       float x4[4] = {vv[0], vv[1], vv[2], vv[3]};
       if (vec) {
         if (a.res) { x4[0] += rv[i][0]; x4[1] += rv[i][1]; x4[2] += rv[i][2]; x4[3] += rv[i][3]; }
-        if (!DBG && a.y2) vec_store<4>(a.y2 + oy, x4);
+        if (a.y2) vec_store<4>(a.y2 + oy, x4);
         if (a.relu) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) x4[c] = act_apply(a.relu, x4[c]);
@@ -1729,7 +1686,7 @@ void conv1x1_persist_kernel(const ConvArgs a) {
           if (epp + c < a.THWo) {
             float val = x4[c];
             if (a.res) val += a.res[o + c];
-            if (!DBG && a.y2) a.y2[oy + c] = val;
+            if (a.y2) a.y2[oy + c] = val;
             if (a.relu) val = act_apply(a.relu, val);
             a.y[oy + c] = val;
           }
@@ -1738,63 +1695,34 @@ void conv1x1_persist_kernel(const ConvArgs a) {
     }
   };
 
-  // prologue: k-tiles 0 .. PD-1 on their way to registers, k-tile 0 in ring stage 0 before the first barrier
-  int loaded = 0;
-  [&]<int... I>(std::integer_sequence<int, I...>) {
-    ((loaded < total ? (load_next(std::integral_constant<int, I>{}), ++loaded, 0) : 0), ...);
-  }(std::make_integer_sequence<int, PD>{});
-  write_stage(std::integral_constant<int, 0>{}, 0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // prologue: every loader wave has its first k-tile on the way; k-tile 0 is in ring stage 0 before the first barrier
+  int w_q = lw;  // the k-tile in this wave's registers (written to LDS in interval w_q - 1)
+  if (p_q < total) load_ktile();
+  if (lw == 0) {
+    write_ktile(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    w_q = 4;
+    if (p_q < total) load_ktile();
+  }
   {
     constexpr int fin = 2;  // the k-tile interval (of the NEXT tile) in which a picked-up tile is finished (nk >= 4: the launcher checks)
     int kt = 0, tile = t0;
-    bool have = false;     // a finished tile of this workgroup is waiting in the staging area / in this thread's registers
-    unsigned long long dbg_bar = 0, dbg_vm = 0, dbg_t0 = 0, dbg_start = 0;
-    if constexpr (DBG) dbg_start = __builtin_amdgcn_s_memtime();
-    // one interval = the time between two barriers; k-tile q lives in register set q % PD until the interval before it is multiplied.
-    // (The register set is picked by a wave-uniform branch around the few load / ds_write instructions, so that the epilogue code
-    // below exists once.)
-    using c0 = std::integral_constant<int, 0>;
-    using c1 = std::integral_constant<int, 1>;
-    using c2 = std::integral_constant<int, 2>;
-    static_assert(PD == 3, "register sets");
-    int dq = 0;  // q % PD
+    bool have = false;     // a finished tile of this workgroup is waiting in the staging area
     for (int q = 0; q < total; ++q) {
-      if constexpr (DBG) dbg_t0 = __builtin_amdgcn_s_memtime();
       asm volatile("s_barrier" ::: "memory");  // releases k-tile q to the MFMA waves; they are done with ring stage (q - 1) & 1
-      if constexpr (DBG) dbg_bar += __builtin_amdgcn_s_memtime() - dbg_t0;
-      if (loaded < total) {  // (set dq held k-tile q: written to LDS in the previous interval)
-        if (dq == 0) load_next(c0{});
-        else if (dq == 1) load_next(c1{});
-        else load_next(c2{});
-        ++loaded;
-      }
       if (have) {
         if (kt == 0) pick_up(tile - 1);  // staged after the previous tile's last barrier, visible since this one
         if (kt == fin) finish();
       }
-      const int dn = dq == PD - 1 ? 0 : dq + 1;
-      if (q + 1 < total) {  // k-tile q + 1 into the stage the MFMA waves have just left
-        if constexpr (DBG) dbg_t0 = __builtin_amdgcn_s_memtime();
-        if (dn == 0) write_stage(c0{}, (q + 1) & 1);
-        else if (dn == 1) write_stage(c1{}, (q + 1) & 1);
-        else write_stage(c2{}, (q + 1) & 1);
+      if (w_q == q + 1 && q + 1 < total) {  // this wave's turn: k-tile q + 1 into the stage the MFMA waves have just left
+        write_ktile((q + 1) & 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (DBG) dbg_vm += __builtin_amdgcn_s_memtime() - dbg_t0;
+        w_q += 4;
+        if (p_q < total) load_ktile();
       }
-      dq = dn;
       if (++kt == nk) { kt = 0; ++tile; have = true; }
     }
     asm volatile("s_barrier" ::: "memory");
-    if constexpr (DBG) {
-      if (tid == 256) {
-        unsigned long long* dd = reinterpret_cast<unsigned long long*>(a.y2) + (size_t)blockIdx.x * 8;
-        dd[4] = __builtin_amdgcn_s_memtime() - dbg_start;
-        dd[5] = dbg_bar;
-        dd[6] = dbg_vm;
-      }
-      return;
-    }
     pick_up(t1 - 1);
     finish();
   }
@@ -2731,7 +2659,7 @@ static int persist_wgs_per_cu(int algo) { return ((algo - ADVHIP_ALGO_PERSIST_BA
 
 static void tile_of(int algo, int* BM, int* BN, int* BK) {
   if (algo == ADVHIP_ALGO_TSPAN_128x64) { *BM = 128; *BN = 64; *BK = 16; return; }
-  if (is_persist(algo)) { *BM = (persist_tile(algo) == 2 || persist_tile(algo) == 5 || persist_tile(algo) == 6) ? 128 : 64; *BN = 64; *BK = 16; return; }
+  if (is_persist(algo)) { *BM = persist_tile(algo) == ADVHIP_ALGO_IGEMM_128x64 ? 128 : 64; *BN = 64; *BK = 16; return; }
   if (algo >= ADVHIP_ALGO_DMA2_BASE) algo -= ADVHIP_ALGO_DMA2_BASE;
   if (algo >= ADVHIP_ALGO_BF16X3_BASE) algo -= ADVHIP_ALGO_BF16X3_BASE;
   if (algo >= ADVHIP_ALGO_DMA4_BASE) algo -= ADVHIP_ALGO_DMA4_BASE;
@@ -2747,7 +2675,7 @@ static void tile_of(int algo, int* BM, int* BN, int* BK) {
 // (e.g. DMA_BASE + 5) are rejected up front: a launch switch that fell through would return OK with y unwritten.
 static bool instantiated(int algo) {
   if (algo == ADVHIP_ALGO_TSPAN_128x64) return true;
-  if (algo >= ADVHIP_ALGO_PERSIST_BASE) return is_persist(algo) && (persist_tile(algo) == 2 || persist_tile(algo) == 3 || persist_tile(algo) == 5 || persist_tile(algo) == 6 || persist_tile(algo) == 7);
+  if (algo >= ADVHIP_ALGO_PERSIST_BASE) return is_persist(algo) && (persist_tile(algo) == ADVHIP_ALGO_IGEMM_128x64 || persist_tile(algo) == ADVHIP_ALGO_IGEMM_64x64) && persist_wgs_per_cu(algo) <= 3;
   auto tile_in = [](int t, unsigned mask) { return t >= 1 && t <= 8 && ((mask >> t) & 1u); };
   constexpr unsigned ALL = 0x1FEu, NO5 = ALL & ~(1u << 5);
   if (algo >= ADVHIP_ALGO_DMA2_BASE) return tile_in(algo - ADVHIP_ALGO_DMA2_BASE, NO5);
@@ -3104,9 +3032,8 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
     g = g / 8 * 8;
     if (g < 8) g = 8;
     const dim3 pgrid((unsigned)g);
-    switch (persist_tile(c.algo)) {  // (experiment: ring depth per id)
-      case 2: case 6: hipLaunchKernelGGL((conv1x1_persist_kernel<128, 64, 2>), pgrid, dim3(512), 0, st, a); break;
-      case 5: hipLaunchKernelGGL((conv1x1_persist_kernel<128, 64, 2, true>), pgrid, dim3(512), 0, st, a); break;  // (diagnostic: cycle stamps into y_preact)
+    switch (persist_tile(c.algo)) {
+      case ADVHIP_ALGO_IGEMM_128x64: hipLaunchKernelGGL((conv1x1_persist_kernel<128, 64, 2>), pgrid, dim3(512), 0, st, a); break;
       default: hipLaunchKernelGGL((conv1x1_persist_kernel<64, 64, 2>), pgrid, dim3(512), 0, st, a); break;
     }
     return check_launch("conv3d persistent");

@@ -45,6 +45,18 @@ MIN_CHANNELS_INFER = int(os.environ.get("ADV_MGFN_HIP_MIN_CHANNELS", "64"))
 MIN_CHANNELS_TRAIN = int(os.environ.get("ADV_MGFN_HIP_MIN_CHANNELS_TRAIN", "64"))
 
 
+# ADV_MGFN_STRICT=1: a GPU activation that misses the HIP kernels' shape rules raises instead of taking the torch expression of the
+# same arithmetic (modeling_mgfn.py's `_pointwise_torch` / `_conv_k_torch` / einsum attention / var_mean norms -- the path of
+# non-default architectures: odd channel counts, B*T % 16 != 0 with autograd, a tensor on another device than the current one)
+STRICT = os.environ.get("ADV_MGFN_STRICT", "0") == "1"
+
+
+def torch_path(x: torch.Tensor, what: str) -> None:
+    """Called where modeling_mgfn.py is about to run a layer on torch ops."""
+    if STRICT and x.is_cuda:
+        raise _lib.HipExtensionError(f"ADV_MGFN_STRICT=1: {what} on {tuple(x.shape)} would run on torch ops (outside the HIP kernels' shape rules, see mgfn_ops.eligible)")
+
+
 def _on_current_device(x: torch.Tensor) -> bool:
     """The kernels launch on the CURRENT device's stream: a tensor on another GPU takes the torch ops instead."""
     return x.is_cuda and x.device.index == torch.cuda.current_device()

@@ -89,6 +89,7 @@ def _pointwise(conv: nn.Conv1d, x: torch.Tensor, residual: Optional[torch.Tensor
 
 
 def _pointwise_torch(conv: nn.Conv1d, x: torch.Tensor) -> torch.Tensor:
+    mgfn_ops.torch_path(x, f"1x1 Conv1d {conv.weight.shape[1]} -> {conv.weight.shape[0]}")
     c, b, t = x.shape
     y = torch.matmul(conv.weight[:, :, 0], x.reshape(c, b * t))
     if conv.bias is not None:
@@ -106,6 +107,7 @@ def _conv_k(conv: nn.Conv1d, x: torch.Tensor, residual: Optional[torch.Tensor] =
 
 
 def _conv_k_torch(conv: nn.Conv1d, x: torch.Tensor) -> torch.Tensor:
+    mgfn_ops.torch_path(x, f"k = {conv.weight.shape[2]} Conv1d {conv.weight.shape[1]} -> {conv.weight.shape[0]}")
     o, c, k = conv.weight.shape
     _, b, t = x.shape
     xp = F.pad(x, (k // 2, k // 2))
@@ -129,6 +131,7 @@ class MGFNLayerNorm(nn.Module):
     def forward(self, x):  # x: (C, B, T)
         if mgfn_ops.fused_ok(x):  # one HIP launch forward, one backward (csrc/mgfn.hip)
             return mgfn_ops.chan_layernorm(x, self.g, self.b, self.eps)
+        mgfn_ops.torch_path(x, "channel LayerNorm")
         var, mean = torch.var_mean(x, dim=0, unbiased=False, keepdim=True)
         return (x - mean) / (var.sqrt() + self.eps) * self.g.view(-1, 1, 1) + self.b.view(-1, 1, 1)
 
@@ -223,6 +226,7 @@ class GlanceAttention(nn.Module):
         qkv = _pointwise(self.to_qkv, self.norm(x))
         if mgfn_ops.glance_attention_ok(qkv, self.heads, self.dim_head):  # scale, sim, softmax, v attn^T, layout: one HIP launch
             return _pointwise(self.to_out, mgfn_ops.glance_attention_core(qkv, self.heads, self.dim_head, self.scale), residual)
+        mgfn_ops.torch_path(x, "Glance attention core (T != 32 or dim_head != 64)")
         qkv = qkv.view(3, self.heads, self.dim_head, b, n)
         q, k, v = (t.permute(2, 0, 1, 3) for t in qkv.unbind(0))  # (b, h, d, n)
         sim = torch.matmul((q * self.scale).transpose(-1, -2), k)  # (b, h, i, j)

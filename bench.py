@@ -303,8 +303,14 @@ def main():
         from anomaly_detection_on_video_amd.train_graph import GraphedTrainStep
 
         scorer.train()
-        # (the runner's optimizer on GPU parameters, runner.configure_optimizers: fused update, device-side step counters)
-        opt = torch.optim.Adam(scorer.parameters(), lr=1e-3, weight_decay=5e-4, fused=True, capturable=True)
+        # (the runner's optimizer on GPU parameters, runner.configure_optimizers: torch.optim.Adam's rule as one HIP launch per 80
+        # tensors, device-side step counters; ADV_HIP_ADAM=0: torch's fused capturable Adam)
+        if os.environ.get("ADV_HIP_ADAM", "1") == "1":
+            from anomaly_detection_on_video_amd.optim import HipAdam
+
+            opt = HipAdam(scorer.parameters(), lr=1e-3, weight_decay=5e-4)
+        else:
+            opt = torch.optim.Adam(scorer.parameters(), lr=1e-3, weight_decay=5e-4, fused=True, capturable=True)
         vb = torch.rand(32, 10, 32, 2048, device=dev, generator=gen) * 3
         vb = torch.cat([vb, vb.norm(dim=3, keepdim=True)], dim=3)
         al, nl = torch.ones(16, device=dev), torch.zeros(16, device=dev)
@@ -332,6 +338,7 @@ def main():
         tflop = 3 * 2 * 293.3e9 / 1e12  # forward 293.3 GMAC, backward = 2 x forward
         mgfn_train = {"workload": "run.py MIL scorer + losses, fwd+bwd+Adam, (32,10,32,2049) fp32, 1 GPU", "ms_per_step": round(ms, 3),
                       "mode": "one HIP graph replay per step (train_graph.GraphedTrainStep, what runner.Trainer runs)" if step.graph is not None else "eager",
+                      "optimizer": type(opt).__name__,
                       "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 3),
                       "tflop_per_step": round(tflop, 3), "achieved_tflops": round(tflop / ms * 1e3, 2),
                       "frac_of_f32_mfma_peak": round(tflop / ms * 1e3 / PEAK_F32_MFMA_TFLOPS, 4)}

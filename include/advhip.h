@@ -60,11 +60,13 @@ extern "C" {
  * for (kt,1,1) stride-1 "same" convs: the temporal taps of a tile re-read the same activation rows from L1/L2 instead of
  * three far-apart tiles fetching them from HBM.  Unsplit; T even. */
 #define ADVHIP_ALGO_TSPAN_128x64 192
-/* + tile id (ADVHIP_ALGO_IGEMM_128x64 or _64x64) + 8 * (W - 1): the PERSISTENT form of the LDS-DMA kernel for unsplit 1x1x1
- * stride-1 convs on 16-byte aligned rows (the `conv3` + residual launches, src/i3d.py:85-89, 108-121): W workgroups per compute
- * unit (1..4) that stay for the whole launch; each walks a contiguous share of the output tiles with the LDS-DMA ring running
- * across tile boundaries (3 stages) and an epilogue staging area of its own.  Same k order and accumulation chain as the other
- * families: bit-identical results.  Never chosen by ADVHIP_ALGO_AUTO. */
+/* + tile id (ADVHIP_ALGO_IGEMM_128x64 or _64x64) + 8 * (W - 1), W = 1..3 workgroups per compute unit: a PERSISTENT, wave-specialised
+ * kernel for unsplit 1x1x1 stride-1 convs on 16-byte aligned rows with K >= 64 (the `conv3` + residual launches,
+ * src/i3d.py:85-89, 108-121): eight-wave workgroups that stay for the whole launch and walk a share of the output tiles; four waves
+ * only multiply, four fetch the operands (plain loads -> registers -> a two-stage LDS ring, four k-tiles ahead, across tile
+ * boundaries) and run the epilogue of the previous tile beside the next tile's MFMAs.  Same k order and accumulation chain as the
+ * other families: bit-identical results.  No LayerNorm fold / GELU-backward operand.  OPT-IN and never chosen by ADVHIP_ALGO_AUTO
+ * or the tuned table: measured slower than the one-tile kernels on the B = 32 plan (profiles/r04_persist_kernel_study.md). */
 #define ADVHIP_ALGO_PERSIST_BASE 224
 
 typedef struct advhip_conv3d_desc {

@@ -1,6 +1,7 @@
-"""The persistent LDS-DMA kernels (ADVHIP_ALGO_PERSIST_BASE, csrc/conv_igemm.hip: conv1x1_persist_kernel) -- workgroups that
-stay for the whole launch and walk a share of the output tiles with the operand ring running across tile boundaries -- for
-the 1x1x1 stride-1 convs of the Bottlenecks (/root/reference/src/i3d.py:85-89, 108-121).  Run with -m gpu on an MI355X.
+"""The persistent, wave-specialised kernels (ADVHIP_ALGO_PERSIST_BASE, csrc/conv_igemm.hip: conv1x1_persist_kernel; opt-in, see
+profiles/r04_persist_kernel_study.md) -- eight-wave workgroups that stay for the whole launch and walk a share of the output tiles,
+four waves multiplying, four fetching operands across tile boundaries and finishing the previous tile -- for the 1x1x1 stride-1
+convs of the Bottlenecks (/root/reference/src/i3d.py:85-89, 108-121).  Run with -m gpu on an MI355X.
 
   * against the CPU oracle (conv + eval BN + residual + ReLU) on the small shapes every other family is checked on;
   * BIT-IDENTICAL to the one-tile-per-workgroup LDS-DMA kernel (same operands, k order and accumulation chain) on shapes
@@ -139,7 +140,11 @@ def test_persistent_family_rejects_what_it_does_not_take():
     pc1, _ = _pack("rej.ok", 64, 64)
     with pytest.raises(_lib.HipExtensionError):
         ops.conv3d_bn_act(x, pc1, algo=algo, splits=2)
-    for bad in (_lib.ALGO_PERSIST_BASE, _lib.ALGO_PERSIST_BASE + 1, _lib.ALGO_PERSIST_BASE + 4, _lib.ALGO_PERSIST_BASE + 32 + 2):
+    pc32, _ = _pack("rej.k32", 32, 64)  # K = 32: two k-tiles per tile, the hand-over schedule needs four
+    with pytest.raises(_lib.HipExtensionError, match="K >= 64"):
+        ops.conv3d_bn_act(synth_tensor("pz.rej.x32", (2, 32, 4, 6, 6)).to(dev), pc32, algo=algo)
+    for bad in (_lib.ALGO_PERSIST_BASE, _lib.ALGO_PERSIST_BASE + 1, _lib.ALGO_PERSIST_BASE + 4, _lib.ALGO_PERSIST_BASE + 5, _lib.ALGO_PERSIST_BASE + 24 + 2,
+                _lib.ALGO_PERSIST_BASE + 32 + 2):
         with pytest.raises(_lib.HipExtensionError, match="not instantiated"):
             ops.conv3d_bn_act(x, pc1, algo=bad)
     y = ops.conv3d_bn_act(x, pc1, algo=algo)

@@ -331,7 +331,8 @@ def test_end_to_end_extract_segment_train_auc(tmp_path):
     assert 0.0 <= gpu_auc <= 1.0
 
 
-def test_graphed_training_steps_equal_eager_steps_bit_for_bit():
+@pytest.mark.parametrize("optimizer", ["hip", "torch-fused"])
+def test_graphed_training_steps_equal_eager_steps_bit_for_bit(optimizer):
     """train_graph.GraphedTrainStep (the step the Trainer and bench.py run: 3 eager steps, then ONE HIP-graph replay per step)
     against the plain eager loop on an identical model: same batches, keep mask pinned -> after 6 steps the losses and every
     parameter, BatchNorm running statistic and Adam moment must be IDENTICAL (same kernels, same order, same arithmetic;
@@ -345,7 +346,12 @@ def test_graphed_training_steps_equal_eager_steps_bit_for_bit():
         m = m.to(DEV).train()
         ones = torch.ones(2, 32, device=DEV)
         m.injected_keep = (ones, ones)
-        opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-4, fused=True, capturable=True)
+        if optimizer == "hip":  # what runner.configure_optimizers builds on GPU parameters
+            from anomaly_detection_on_video_amd.optim import HipAdam
+
+            opt = HipAdam(m.parameters(), lr=1e-3, weight_decay=5e-4)
+        else:
+            opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-4, fused=True, capturable=True)
         return m, opt
 
     nl, al = torch.zeros(2, device=DEV), torch.ones(2, device=DEV)
