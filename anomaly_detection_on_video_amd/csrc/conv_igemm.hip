@@ -1012,6 +1012,11 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   static_assert(EPI == EPI_STD || (BM == 128 && BN == 64), "pooling epilogues: 128 x 64 tile (wave row = one t plane of the brick)");
   static_assert(EPI != EPI_AVG || (!CHECK && NS == 2 && !U8 && AMODE == 0), "the mean epilogue: 1x1x1 convs on the 2-deep ring");
   static_assert(!U8 || (EPI == EPI_POOL233 && CHECK), "uint8 frame input: the stem + maxpool1 form (an m-tile lies in one crop)");
+  // AMODE 2: the 16-byte-piece form of a 1x1x1 stride-1 conv (ConvArgs::a16) known at COMPILE time: the per-thread position
+  // decode, the window origin and the gather table of the other forms drop out of the prologue -- which a new workgroup executes
+  // beside the older workgroups' MFMA streams (profiles/r01_pmc_notes.md: 4-6 us of a short-K tile's life)
+  constexpr bool A16ONLY = AMODE == 2;
+  static_assert(!A16ONLY || (!CHECK && NS == 2 && !U8 && epi_rows(EPI)), "compile-time a16: unchecked 1x1x1 convs on the 2-deep ring");
   constexpr int BRICK_T = brick_t(EPI), BRICK_H = EPI == EPI_POOL233 ? 4 : 1, BRICK_W = BM / (BRICK_T * BRICK_H);
 
   __shared__ __attribute__((aligned(16))) float smem[SMEM];
@@ -1045,7 +1050,9 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   int pb = 0, pot = 0, poh = 0, pow_ = 0;
   bool pvalid;
   int bk_b = 0, bk_t = 0, bk_h = 0, bk_w = 0;  // brick forms: sample and brick coordinates of this m-tile
-  if constexpr (epi_rows(EPI)) {
+  if constexpr (A16ONLY) {
+    pvalid = false;  // (nothing below needs this thread's own position)
+  } else if constexpr (epi_rows(EPI)) {
     pvalid = m < a.M;
     if (pvalid) {
       pb = (int)a.dTHWo.div((unsigned)m);
@@ -1164,7 +1171,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
 #else
   constexpr int A16_BYTES = 4;
 #endif
-  const bool a16 = CAN16 && a.a16 != 0;
+  const bool a16 = A16ONLY || (CAN16 && a.a16 != 0);
   unsigned vbase16 = OOB;
   if constexpr (CAN16) {
     if (a16) {
@@ -1213,7 +1220,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
         done16 = true;
       }
     }
-    if (!done16) {
+    if constexpr (!A16ONLY) if (!done16) {
 #pragma unroll
       for (int j = 0; j < LA; ++j) {
         if (j * nparts / LA != part) continue;
@@ -1236,7 +1243,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
       sload_entries<4>(a.ktab_s2w, (k0 + wave * 4) * 8, e4);
 #pragma unroll
       for (int i = 0; i < 8; ++i) ent[i] = e4[i];
-    } else {
+    } else if constexpr (!A16ONLY) {
       if (!a16) sload_entries<LA>(ktab2, (k0 + kr * LA) * 8, ent);
     }
   };
@@ -2776,7 +2783,8 @@ static void set_bricks(ConvArgs& a, int nbt, int nbh, int nbw);  // defined with
 template <int BM_, int BN_, int BK_>
 static void launch_dma2(bool nocheck, bool s16, dim3 grid, hipStream_t st, const ConvArgs& a) {
   if (nocheck) {
-    hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, false, 2>), grid, dim3(256), 0, st, a);
+    if (a.a16) hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, false, 2, EPI_STD, false, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, false, 2>), grid, dim3(256), 0, st, a);
     return;
   }
   if constexpr (BK_ == 16) {

@@ -261,3 +261,17 @@ def segment(feature_path: str, seg_outpath: str, seg_length: int = 32) -> None:
         if os.path.exists(savepath):
             continue
         np.save(savepath, segment_array(np.load(os.path.join(feature_path, file)), seg_length))
+
+
+def two_stream_features(rgb_model, flow_model, rgb_clips: torch.Tensor, flow_clips: torch.Tensor) -> torch.Tensor:
+    """(B, 2048) rows of a two-stream I3D (BASELINE config 5): the mean of the RGB backbone's and the flow backbone's
+    (`I3Res50(in_channels=2)`) features of the same crop-clips -- late fusion into the 2 048-d row the MGFN scorer expects
+    (`segment` / `FeatureDataset.add_magnitude` / the scorer downstream are unchanged).  NOT IN THE REFERENCE, which is RGB-only
+    (/root/reference/src/i3d.py:202-209: no flow stem, no fusion rule): unpinned by construction, checked against the oracle's
+    generic arithmetic only.  Both forwards are the fused HIP plan; the mean is one elementwise launch."""
+    if rgb_clips.shape[0] != flow_clips.shape[0] or rgb_clips.shape[2:] != flow_clips.shape[2:]:
+        raise ValueError(f"two_stream_features: RGB clips {tuple(rgb_clips.shape)} and flow clips {tuple(flow_clips.shape)} do not describe the same crop-clips")
+    with torch.no_grad():
+        fr = rgb_model(rgb_clips).reshape(rgb_clips.shape[0], -1)
+        ff = flow_model(flow_clips).reshape(flow_clips.shape[0], -1)
+        return (fr + ff) * 0.5

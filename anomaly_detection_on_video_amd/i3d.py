@@ -127,11 +127,15 @@ class NonLocalBlock(nn.Module):
 class I3Res50(nn.Module):
     MIN_PART = 8  # crop-clips per stream below which splitting a batch over streams does not pay (B=8: -5 %, B=16..32: +2-3 %)
 
-    def __init__(self, block=Bottleneck, layers=[3, 4, 6, 3], use_nl=False):
+    def __init__(self, block=Bottleneck, layers=[3, 4, 6, 3], use_nl=False, in_channels: int = 3):
+        """`in_channels`: 3 = the reference's RGB backbone (src/i3d.py:202-209).  Any other count -- 2 for the (x, y) planes of an
+        optical-flow stream, BASELINE config 5 -- changes the stem's input width only; that is NOT in the reference (it ships no flow
+        stream), so such a model has no reference pin: it is checked against the oracle's generic conv arithmetic."""
         self.inplanes = 64
         super().__init__()
         nonlocal_mod = 2 if use_nl else 1000  # src/i3d.py:219
-        self.conv1 = nn.Conv3d(3, 64, kernel_size=(5, 7, 7), stride=(2, 2, 2), padding=(2, 3, 3), bias=False)
+        self.in_channels = int(in_channels)
+        self.conv1 = nn.Conv3d(self.in_channels, 64, kernel_size=(5, 7, 7), stride=(2, 2, 2), padding=(2, 3, 3), bias=False)
         self.bn1 = nn.BatchNorm3d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool1 = nn.MaxPool3d(kernel_size=(2, 3, 3), stride=(2, 2, 2), padding=(0, 0, 0))
@@ -279,8 +283,8 @@ class I3Res50(nn.Module):
                 "I3Res50 HIP path implements eval-mode BatchNorm (running statistics) only; call .eval() "
                 "as extract_features.load_feature_extraction_model does (extract_features.py:36)"
             )
-        if x.dim() != 5 or x.shape[1] != 3:
-            raise ValueError(f"expected (B,3,T,H,W), got {tuple(x.shape)}")
+        if x.dim() != 5 or x.shape[1] != self.in_channels:
+            raise ValueError(f"expected (B,{self.in_channels},T,H,W), got {tuple(x.shape)}")
         if x.dtype != torch.float32:
             raise _lib.HipExtensionError(f"input dtype {x.dtype}: the backbone computes in fp32")
         if not x.is_cuda:
@@ -347,6 +351,8 @@ class I3Res50(nn.Module):
         57-73, extract_features.py:83-89) -- happens in the load stage of the stem kernel: the fp32 ten-crop tensor never exists."""
         if self.training:
             raise _lib.HipExtensionError("I3Res50 HIP path implements eval-mode BatchNorm only; call .eval()")
+        if self.in_channels != 3:
+            raise _lib.HipExtensionError("forward_frames takes RGB frames: the backbone was built with in_channels != 3")
         if frames.dtype != torch.uint8 or frames.dim() != 4 or not frames.is_cuda:
             raise _lib.HipExtensionError(f"forward_frames wants uint8 (F,H,W,3) frames on the GPU, got {frames.dtype} {tuple(frames.shape)} on {frames.device}")
         self.prepare()

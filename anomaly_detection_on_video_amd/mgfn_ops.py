@@ -961,30 +961,37 @@ class _DWConvT(torch.autograd.Function):
 
 
 class _TokenTaps(torch.autograd.Function):
-    """z = Wt @ Xr^T for Wt (k*O, C) -- the k tap matrices of the 2048 -> 64 token conv stacked -- and Xr (N, C) the scorer's
-    input rows AS STORED (positions x channels, row pitch C + 1: the magnitude column rides along): both operands are
-    contraction-contiguous, i.e. advhip_gemm_nt_f32 reads them in place (MGFNFeatureAmplifier._tokens_by_taps,
-    /root/reference/src/models/mgfn/modeling_mgfn.py:81-93).  Backward: dWt = dZ @ Xr (advhip_bgemm_f32 on the same rows);
-    the input carries no gradient."""
+    """z = Wt @ X^T for Wt (k*O, C) -- the k tap matrices of the 2048 -> 64 token conv stacked -- and X the scorer's input rows AS
+    STORED (`rows`: (N positions, C + 1) contiguous, the magnitude column rides along; MGFNFeatureAmplifier._tokens_by_taps,
+    /root/reference/src/models/mgfn/modeling_mgfn.py:81-93).  Forward: both operands are contraction-contiguous, i.e.
+    advhip_gemm_nt_f32 reads them in place (row pitch C + 1).  Backward: dWt[o, c] = sum_n dZ[o, n] X[n, c] contracts over the
+    positions, along which X is NOT contiguous -- but X as stored IS the conv kernels' A operand for that product (row n = "channel"
+    n of a (N, 1, C + 1) activation, its C + 1 entries the positions): one weight pack of dZ (7.8 MB) and one conv launch with the K
+    slices summed inside; column C of the result (the magnitude column's product) is dropped.  The input carries no gradient."""
 
     @staticmethod
-    def forward(ctx, wt, xr):
-        ctx.save_for_backward(xr)
-        return ops.gemm_nt(wt, xr)
+    def forward(ctx, wt, rows):
+        c = wt.shape[1]
+        ctx.save_for_backward(rows)
+        return ops.gemm_nt(wt, rows[:, :c])
 
     @staticmethod
     def backward(ctx, dz):
-        (xr,) = ctx.saved_tensors
-        return ops.bgemm(dz.contiguous(), xr)[0], None
+        (rows,) = ctx.saved_tensors
+        n, c1 = rows.shape
+        ko = dz.shape[0]
+        wp = pack_kc(dz.contiguous().view(ko, n, 1))                   # [N (padded to 32)][k*O]
+        y = conv_cn(rows.view(n, 1, c1), wp, ko, 1)                    # (k*O, 1, C + 1)
+        return y[:, 0, : c1 - 1], None
 
 
-def token_taps_ok(wt: torch.Tensor, xr: torch.Tensor) -> bool:
-    return (_on_current_device(xr) and xr.dtype == torch.float32 and wt.dtype == torch.float32 and xr.dim() == 2 and xr.stride(1) == 1
-            and wt.shape[1] % 16 == 0 and wt.shape[1] == xr.shape[1] and not xr.requires_grad)
+def token_taps_ok(wt: torch.Tensor, rows: torch.Tensor) -> bool:
+    return (_on_current_device(rows) and rows.dtype == torch.float32 and wt.dtype == torch.float32 and rows.dim() == 2 and rows.is_contiguous()
+            and wt.shape[1] % 16 == 0 and wt.shape[1] + 1 == rows.shape[1] and wt.shape[0] % 64 == 0 and not rows.requires_grad)
 
 
-def token_taps(wt: torch.Tensor, xr: torch.Tensor) -> torch.Tensor:
-    return _TokenTaps.apply(wt.contiguous(), xr)
+def token_taps(wt: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
+    return _TokenTaps.apply(wt.contiguous(), rows)
 
 
 class _AmpCombine(torch.autograd.Function):

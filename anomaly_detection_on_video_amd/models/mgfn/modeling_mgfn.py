@@ -193,9 +193,9 @@ class MGFNFeatureAmplifier(nn.Module):
         conv = self.to_tokens
         o, c, k = conv.weight.shape
         wt = conv.weight.permute(2, 0, 1).reshape(k * o, c)              # the k tap matrices, stacked
-        xr = rows[:, :c] if rows is not None else None                    # (B*T, C) rows of pitch C + 1, read in place
-        if xr is not None and mgfn_ops.token_taps_ok(wt, xr):
-            z = mgfn_ops.token_taps(wt, xr).view(k, o, b, t)              # advhip_gemm_nt_f32 forward, advhip_bgemm_f32 weight gradient
+        if rows is not None and rows.shape[1] == c + 1 and mgfn_ops.fused_ok(x) and mgfn_ops.token_taps_ok(wt, rows.contiguous()):
+            # (B*T, C + 1) rows read in place: advhip_gemm_nt_f32 forward, one conv launch on the same rows for the weight gradient
+            z = mgfn_ops.token_taps(wt, rows.contiguous()).view(k, o, b, t)
         else:
             xv = x[:c].reshape(c, b * t)                                  # (C, B*T) view of the (B*T, C+1) rows: strides (1, C+1)
             z = torch.matmul(wt, xv).view(k, o, b, t)

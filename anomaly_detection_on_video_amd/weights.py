@@ -61,7 +61,7 @@ def nonlocal_positions(use_nl: bool):
     return {("layer2", 1), ("layer2", 3), ("layer3", 1), ("layer3", 3), ("layer3", 5)} if use_nl else set()
 
 
-def i3d_state_dict_spec(use_nl: bool = False) -> Iterable[Tuple[str, Tuple[int, ...], str]]:
+def i3d_state_dict_spec(use_nl: bool = False, in_channels: int = 3) -> Iterable[Tuple[str, Tuple[int, ...], str]]:
     """(key, shape, kind) for every entry of the reference I3Res50 state dict.
 
     Topology restated from `src/i3d.py:198-300` (layers [3,4,6,3]; temporal kernels
@@ -75,7 +75,7 @@ def i3d_state_dict_spec(use_nl: bool = False) -> Iterable[Tuple[str, Tuple[int, 
         yield f"{prefix}.running_var", (c,), "bn_var"
         yield f"{prefix}.num_batches_tracked", (), "bn_count"
 
-    yield "conv1.weight", (64, 3, 5, 7, 7), "conv"
+    yield "conv1.weight", (64, in_channels, 5, 7, 7), "conv"  # (3: the reference's RGB stem; 2: a flow stream's, BASELINE config 5)
     yield from bn("bn1", 64)
     inplanes = 64
     cfg = [
@@ -105,9 +105,9 @@ def i3d_state_dict_spec(use_nl: bool = False) -> Iterable[Tuple[str, Tuple[int, 
             inplanes = planes * 4
 
 
-def synth_i3d_state_dict(salt: int = 0, use_nl: bool = False) -> Dict[str, torch.Tensor]:
+def synth_i3d_state_dict(salt: int = 0, use_nl: bool = False, in_channels: int = 3) -> Dict[str, torch.Tensor]:
     sd: Dict[str, torch.Tensor] = {}
-    for key, shape, kind in i3d_state_dict_spec(use_nl):
+    for key, shape, kind in i3d_state_dict_spec(use_nl, in_channels):
         if kind == "conv":
             fan_in = int(np.prod(shape[1:]))
             # uniform[-a,a] has variance a^2/3; aim at var = 2/fan_in (ReLU-preserving)

@@ -109,7 +109,8 @@ def test_the_step_ran_on_the_benchmarked_kernels(step_records):
     for cin, cout, k, npos, algo, splits in stage2:  # (128 x 128 tiles for the 4096-wide outputs, 128 x 64 for the 1024-wide)
         assert npos == n and algo == (mgfn_ops.ALGO_WIDE if cout == 4096 else mgfn_ops.ALGO) and splits == 1, (cin, cout, k, npos, algo, splits)
     # weight gradients dW = dY X^T: contraction over all 10 240 positions, stage-2 shapes present
-    assert nts and all(kk == n for _a, _b, kk in nts), nts[:4]
+    # (and ONE product over the 2 048 input channels: the token conv's tap GEMM on the input rows as stored, modeling_mgfn._tokens_by_taps)
+    assert (192, n, 2048) in nts and all(kk == n for a_, b_, kk in nts if (a_, b_, kk) != (192, n, 2048)), nts[:4]
     assert (4096, 1024, n) in nts and (1024, 4096, n) in nts and (1024, 3072, n) in nts
 
 

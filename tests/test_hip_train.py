@@ -413,10 +413,13 @@ def test_hip_adam_tracks_torch_adam_and_shares_its_state_layout():
     # state interchange: torch's state into HipAdam (what a resumed reference checkpoint does) and back
     hip2_p = [p.detach().clone().requires_grad_() for p in ref_p]
     hip2 = HipAdam(hip2_p, lr=1e-3, weight_decay=5e-4)
-    hip2.load_state_dict(ref.state_dict())
+    import copy
+
+    # (deep copies, as a checkpoint file gives: Optimizer.load_state_dict keeps the very `step` tensors of the dict it is handed)
+    hip2.load_state_dict(copy.deepcopy(ref.state_dict()))
     ref2_p = [p.detach().clone().requires_grad_() for p in ref_p]
     ref2 = torch.optim.Adam(ref2_p, lr=1e-3, weight_decay=5e-4)
-    ref2.load_state_dict(hip.state_dict())
+    ref2.load_state_dict(copy.deepcopy(hip.state_dict()))
     for a, b, c in zip(ref_p, hip2_p, ref2_p):
         gr = torch.randn(a.shape, generator=g).to(dev)
         a.grad, b.grad, c.grad = gr.clone(), gr.clone(), gr.clone()

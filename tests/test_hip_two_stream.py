@@ -1,0 +1,152 @@
+"""BASELINE config 5 as far as one GPU goes: a two-stream (RGB + flow) I3D -> MIL scorer path.  NOT IN THE REFERENCE -- it ships an
+RGB backbone only (/root/reference/src/i3d.py:202-209) -- so nothing here has a reference pin: the 2-channel stem and the
+whole 2-channel backbone are checked against the oracle's generic arithmetic (F.conv3d has no notion of "RGB"), and the end-to-end
+miniature (extract both streams -> average -> segment -> train -> AUC) against the CPU oracle's scores.  Run with -m gpu."""
+import io
+import json
+import os
+import zipfile
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close_elementwise, rel_err
+from anomaly_detection_on_video_amd.weights import synth_i3d_state_dict, synth_input, synth_tensor
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def test_two_channel_stem_vs_oracle():
+    from anomaly_detection_on_video_amd import ops
+    from oracle import i3d_oracle
+
+    cin, cout, k, s, p = 2, 64, (5, 7, 7), (2, 2, 2), (2, 3, 3)
+    x = synth_tensor("flow.stem.x", (3, cin, 16, 40, 44), scale=2.0)
+    wt = synth_tensor("flow.stem.w", (cout, cin) + k, scale=float(np.sqrt(6.0 / (cin * 245))))
+    g = synth_tensor("flow.stem.g", (cout,), scale=0.5, offset=1.0)
+    be, mu = synth_tensor("flow.stem.b", (cout,), scale=0.25), synth_tensor("flow.stem.m", (cout,), scale=0.25)
+    var = synth_tensor("flow.stem.v", (cout,), scale=0.5, offset=1.0)
+    ref = i3d_oracle.conv_bn_act(x, wt, g, be, mu, var, s, p, None, True)
+    pc = ops.pack_conv(wt.to(DEV), g.to(DEV), be.to(DEV), mu.to(DEV), var.to(DEV), 1e-5, s, p, name="flow.stem")
+    got = ops.conv3d_bn_act(x.to(DEV), pc, relu=True)
+    assert rel_err(got.cpu(), ref) < 2e-5
+    # ... and fused with maxpool1, as the plan runs it
+    pooled = ops.conv3d_bn_relu_maxpool233(x.to(DEV), pc)
+    assert torch.equal(pooled, ops.maxpool3d(got, (2, 3, 3), (2, 2, 2)))
+
+
+def test_two_channel_backbone_vs_oracle():
+    from anomaly_detection_on_video_amd.i3d import I3Res50
+    from oracle import i3d_oracle
+
+    sd = synth_i3d_state_dict(salt=7, in_channels=2)
+    m = I3Res50(in_channels=2)
+    m.load_state_dict(sd, strict=True)
+    m = m.eval().to(DEV)
+    x = synth_input((2, 2, 16, 64, 64), 9, name="flow")
+    y = m(x.to(DEV)).cpu()
+    ref = i3d_oracle.i3d_forward(x, sd)
+    assert y.shape == (2, 2048, 1, 1, 1)
+    assert rel_err(y, ref) < 1e-4
+    assert_close_elementwise(y, ref, 1e-3, 1e-3)
+    with pytest.raises(ValueError):
+        m(synth_input((1, 3, 16, 64, 64), 1).to(DEV))  # an RGB clip into the flow backbone
+
+
+def _streams(video_u8: torch.Tensor):
+    """(n_clips, 10, 16, 3, H, W) uint8 -> RGB crop-clips (n*10, 3, 16, H, W) normalised as the reference does, and a synthetic
+    "flow": channel 0 the temporal difference, channel 1 the horizontal gradient of the grey frames (two planes like (u, v))."""
+    n = video_u8.shape[0]
+    rgb = ((video_u8.float() - 114.75) / 57.375).permute(0, 1, 3, 2, 4, 5).reshape(n * 10, 3, 16, *video_u8.shape[-2:])
+    grey = rgb.mean(dim=1)                                        # (n*10, 16, H, W)
+    dt = torch.diff(grey, dim=1, append=grey[:, -1:])
+    dx = torch.diff(grey, dim=3, append=grey[:, :, :, -1:])
+    return rgb.contiguous(), torch.stack([dt, dx], dim=1).contiguous()
+
+
+def test_two_stream_extract_segment_train_auc_miniature(tmp_path):
+    import run
+    from anomaly_detection_on_video_amd import extract, metrics
+    from anomaly_detection_on_video_amd.dataset import build_feature_dataset
+    from anomaly_detection_on_video_amd.gt import frame_ground_truth
+    from anomaly_detection_on_video_amd.i3d import I3Res50
+    from oracle import i3d_oracle, mgfn_oracle
+
+    torch.manual_seed(0)
+    rgb_bb = I3Res50()
+    rgb_bb.load_state_dict(synth_i3d_state_dict())
+    flow_sd = synth_i3d_state_dict(salt=7, in_channels=2)
+    flow_bb = I3Res50(in_channels=2)
+    flow_bb.load_state_dict(flow_sd)
+    rgb_bb, flow_bb = rgb_bb.eval().to(DEV), flow_bb.eval().to(DEV)
+    g = torch.Generator().manual_seed(23)
+
+    def video(n_clips, burst=None):
+        v = torch.randint(60, 140, (n_clips, 10, 16, 3, 32, 32), generator=g, dtype=torch.uint8)
+        if burst is not None:
+            v[burst[0] : burst[1]] = torch.randint(200, 256, v[burst[0] : burst[1]].shape, generator=g, dtype=torch.uint8)
+        return v
+
+    def features(v):  # (n_clips, 10, 2048): the mean of the two streams' rows
+        rgb, flow = _streams(v)
+        f = extract.two_stream_features(rgb_bb, flow_bb, rgb.to(DEV), flow.to(DEV))
+        return f.reshape(v.shape[0], 10, 2048).cpu().numpy()
+
+    # the fusion itself against the oracle: mean of the two oracle forwards
+    v0 = video(1)
+    rgb0, flow0 = _streams(v0)
+    want = 0.5 * (i3d_oracle.i3d_forward(rgb0[:2], synth_i3d_state_dict()) + i3d_oracle.i3d_forward(flow0[:2], flow_sd)).reshape(2, 2048)
+    got = extract.two_stream_features(rgb_bb, flow_bb, rgb0[:2].to(DEV), flow0[:2].to(DEV)).cpu()
+    assert rel_err(got, want) < 1e-4
+    with pytest.raises(ValueError):
+        extract.two_stream_features(rgb_bb, flow_bb, rgb0[:2].to(DEV), flow0[:3].to(DEV))
+
+    root = tmp_path / "corpus"
+    os.makedirs(root)
+
+    def put(z, name, arr):
+        buf = io.BytesIO()
+        np.save(buf, arr.astype(np.float32))
+        z.writestr(name, buf.getvalue())
+
+    with zipfile.ZipFile(root / "train.zip", "w") as z:
+        for i in range(3):
+            put(z, f"train/Normal_Videos{i:03d}_x264_i3d.npy", extract.segment_array(features(video(4)), 32))
+        for i in range(3):
+            put(z, f"train/Abuse{i:03d}_x264_i3d.npy", extract.segment_array(features(video(5, burst=(1, 3))), 32))
+    gt = {}
+    with zipfile.ZipFile(root / "test.zip", "w") as z:
+        for i in range(4):
+            n = 4 + i
+            if i % 2:
+                f, name, ev = features(video(n, burst=(1, 3))), f"Burglary{i:03d}_x264", ((16, 47), (-1, -1))
+            else:
+                f, name, ev = features(video(n)), f"Normal_Videos_{900 + i}_x264", ((-1, -1), (-1, -1))
+            put(z, f"test/{name}_i3d.npy", f)
+            gt[name] = frame_ground_truth(n, *ev)
+    with open(root / "ground_truth.json", "w") as f:
+        json.dump(gt, f)
+
+    trainer = run.main([
+        "data=synthetic", f"data.local_path={root}", "data.batch_size=2", "trainer.cls.max_epochs=2",
+        f"trainer.callbacks.model_checkpoint.dirpath={tmp_path / 'ckpt'}", "trainer.callbacks.model_checkpoint.every_n_epochs=1",
+        f"trainer.logger.jsonl.path={tmp_path / 'log.jsonl'}",
+    ])
+    vals = [h for h in trainer.history if "valid/rec_auc" in h]
+    assert len(vals) == 2
+    gpu_auc = vals[-1]["valid/rec_auc"]
+    state = torch.load(tmp_path / "ckpt" / "last.ckpt", map_location="cpu", weights_only=False)["state_dict"]
+    state = {k[len("model."):]: v for k, v in state.items()}
+    ds = build_feature_dataset("test", local_path=str(root), filename="test.zip", dynamic_load=False)
+    preds, labels = [], []
+    for i in range(len(ds)):
+        item = ds[i]
+        video_t = torch.from_numpy(item["feature"]).unsqueeze(0).permute(0, 2, 1, 3)
+        with torch.no_grad():
+            preds.append(mgfn_oracle.mgfn_forward(video_t.float(), state).scores.reshape(-1).numpy())
+        labels.append(item["label"])
+    cpu_auc, _ = metrics.frame_level_auc(preds, labels, 16)
+    assert abs(cpu_auc - gpu_auc) < 2e-3, (cpu_auc, gpu_auc)
+    assert 0.0 <= gpu_auc <= 1.0
