@@ -46,8 +46,14 @@ def _single_process(world, shape="small"):
     lb = cfg["local_batch"]
     single = ExtractScoreStream(bb, sc, clips_per_video=cfg["clips_per_video"], ncrops=cfg["ncrops"], local_batch=lb, world=1, rank=0)
     rows, scores = [], {}
-    for i in range(0, x.shape[0], lb):  # the same blocks of LOCAL_BATCH crop-clips per launch, stream order
-        g, sl = single.step(x[i : i + lb].to("cuda:0"))
+    # the same blocks of LOCAL_BATCH crop-clips per launch, stream order, through the same entry point as the ranks (step_async:
+    # whole-batch launches on the stream's lanes -- the synchronous step() spreads a batch of >= 16 over two streams of half
+    # batches, i.e. other table entries with other K slices: equal within tolerance, not bit for bit)
+    handles = [single.step_async(x[i : i + lb].to("cuda:0")) for i in range(0, x.shape[0], lb)]
+    single.drain()
+    torch.cuda.synchronize()
+    for h in handles:
+        g, sl = h.result()
         rows.append(g.cpu())
         for v, s in sl:
             scores[v] = s.cpu()

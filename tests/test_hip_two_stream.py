@@ -33,8 +33,11 @@ def test_two_channel_stem_vs_oracle():
     got = ops.conv3d_bn_act(x.to(DEV), pc, relu=True)
     assert rel_err(got.cpu(), ref) < 2e-5
     # ... and fused with maxpool1, as the plan runs it
+    from anomaly_detection_on_video_amd import _lib
+
     pooled = ops.conv3d_bn_relu_maxpool233(x.to(DEV), pc)
-    assert torch.equal(pooled, ops.maxpool3d(got, (2, 3, 3), (2, 2, 2)))
+    unsplit = ops.conv3d_bn_act(x.to(DEV), pc, relu=True, algo=_lib.ALGO_DMA2_BASE + _lib.ALGO_IGEMM_64x64, splits=1)  # (same K order as the fused launch)
+    assert torch.equal(pooled, ops.maxpool3d(unsplit, (2, 3, 3), (2, 2, 2)))
 
 
 def test_two_channel_backbone_vs_oracle():
