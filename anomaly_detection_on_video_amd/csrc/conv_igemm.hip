@@ -1010,7 +1010,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   constexpr int SMEM0 = RING > Cfg::ST_FLOATS ? RING : Cfg::ST_FLOATS;
   constexpr int SMEM = SMEM0 > BRICK_FLOATS ? SMEM0 : BRICK_FLOATS;
   static_assert(EPI == EPI_STD || (BM == 128 && BN == 64), "pooling epilogues: 128 x 64 tile (wave row = one t plane of the brick)");
-  static_assert(EPI != EPI_AVG || (!CHECK && NS == 2 && !U8 && AMODE == 0), "the mean epilogue: 1x1x1 convs on the 2-deep ring");
+  static_assert(EPI != EPI_AVG || (!CHECK && NS == 2 && !U8 && (AMODE == 0 || AMODE == 2)), "the mean epilogue: 1x1x1 convs on the 2-deep ring");
   static_assert(!U8 || (EPI == EPI_POOL233 && CHECK), "uint8 frame input: the stem + maxpool1 form (an m-tile lies in one crop)");
   // AMODE 2: the 16-byte-piece form of a 1x1x1 stride-1 conv (ConvArgs::a16) known at COMPILE time: the per-thread position
   // decode, the window origin and the gather table of the other forms drop out of the prologue -- which a new workgroup executes
@@ -3025,7 +3025,8 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
     else hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<BN_, true>), grid, dim3(256), 0, st, a);                   \
     break;
   if (avg_out != nullptr) {
-    hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, false, 2, EPI_AVG>), grid, dim3(256), 0, st, a);
+    // (a.a16 is always set here -- the rows are padded in the M index space -- so the compile-time a16 form applies)
+    hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, false, 2, EPI_AVG, false, 2>), grid, dim3(256), 0, st, a);
     return check_launch("conv3d + mean");
   }
   if (is_persist(c.algo)) {
