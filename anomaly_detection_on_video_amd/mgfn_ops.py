@@ -39,8 +39,8 @@ _CONST: Dict[Tuple, torch.Tensor] = {}
 
 
 # smallest channel count that goes to the HIP GEMMs: 64 = every layer of the default model (stage 0 included: at inference
-# 2.49 vs 2.84 ms per video; in a training step at (32,10,32,2049) 17.60 vs 17.94 ms, round 3).  The 2048 -> 64 token conv
-# keeps a torch GEMM with autograd (MGFNFeatureAmplifier._tokens_by_taps: its weight gradient here would unfold the input)
+# 2.49 vs 2.84 ms per video; in a training step at (32,10,32,2049) 17.60 vs 17.94 ms, round 3).  The 2048 -> 64 token conv has a
+# form of its own on the same kernels (_TokenTaps: the NT GEMM and one conv launch on the input rows as stored)
 MIN_CHANNELS_INFER = int(os.environ.get("ADV_MGFN_HIP_MIN_CHANNELS", "64"))
 MIN_CHANNELS_TRAIN = int(os.environ.get("ADV_MGFN_HIP_MIN_CHANNELS_TRAIN", "64"))
 
