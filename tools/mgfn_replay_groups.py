@@ -17,6 +17,12 @@ segs = [rows[a:b] for a, b in zip(starts[:-1], starts[1:])][-last:]
 def group(n):
     if "advhip::" in n:
         return n.split("advhip::")[1].split("<")[0].split("(")[0]
+    if "adam_multi_kernel" in n:
+        return "adam_multi_kernel"
+    if "fused_dropout" in n:
+        return "torch fused_dropout"
+    if "FillFunctor" in n:
+        return "torch fill"
     if n.startswith("Cijk"):
         return "rocBLAS"
     if "multi_tensor" in n:
