@@ -144,16 +144,25 @@ def test_two_stream_extract_segment_train_auc_miniature(tmp_path):
     state = torch.load(tmp_path / "ckpt" / "last.ckpt", map_location="cpu", weights_only=False)["state_dict"]
     state = {k[len("model."):]: v for k, v in state.items()}
     ds = build_feature_dataset("test", local_path=str(root), filename="test.zip", dynamic_load=False)
+    from anomaly_detection_on_video_amd.models.mgfn import MGFNConfig, MGFNForVideoAnomalyDetection
+
+    scorer = MGFNForVideoAnomalyDetection(MGFNConfig())
+    scorer.load_state_dict(state)
+    scorer = scorer.eval().to(DEV)
     preds, labels = [], []
     for i in range(len(ds)):
         item = ds[i]
         video_t = torch.from_numpy(item["feature"]).unsqueeze(0).permute(0, 2, 1, 3)
         with torch.no_grad():
             preds.append(mgfn_oracle.mgfn_forward(video_t.float(), state).scores.reshape(-1).numpy())
+            got = scorer(video=video_t.float().contiguous().to(DEV)).scores.reshape(-1).cpu().numpy()
+        # the scores themselves, clip by clip: the HIP scorer on the trained weights against the oracle on the same weights
+        assert np.abs(got - preds[-1]).max() < 1e-5, (i, np.abs(got - preds[-1]).max())
         labels.append(item["label"])
     # the GPU scores agree with the oracle's to ~1e-6 (forward only: the weights are the trained ones in both); a near-tie between
     # a positive and a negative clip may rank either way, so the GPU's AUC lies in the band the oracle's scores +- 1e-5 span
     lo, cpu_auc, hi = auc_band(preds, labels, 16, tol=1e-5)
+    # (after two or three epochs on a few dozen clips the scores can sit within 1e-5 of each other: the band is then wide and the
+    # clip-by-clip comparison above is the check)
     assert lo - 1e-9 <= gpu_auc <= hi + 1e-9, (lo, cpu_auc, hi, gpu_auc)
-    assert hi - lo <= 0.1, (lo, hi)  # (the band itself must stay a check)
     assert 0.0 <= gpu_auc <= 1.0
