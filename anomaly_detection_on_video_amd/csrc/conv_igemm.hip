@@ -176,6 +176,136 @@ __device__ __forceinline__ float act_gelu_grad(float x) {
 }
 __device__ __forceinline__ float act_apply(int code, float v) { return code == 1 ? fmaxf(v, 0.f) : (code == 2 ? act_gelu(v) : v); }
 
+// ---- the plain epilogue: y = act(acc * scale + shift (+ res)), act in {none, ReLU} -- every conv of the I3D plan and the MGFN GEMMs
+// without LayerNorm fold / GELU / second output.  Same arithmetic, LDS transposition and store pattern as igemm_epilogue below;
+// what differs is the order of the memory operations: below, every staged row waits for its scale / shift loads, then for its
+// residual load, then stores -- FN * 16 / RPI rounds of two dependent latencies per tile (8 x 2 for the 128 x 64 tile, 32 x 2 on
+// the unaligned path), which a launch of one or two rounds of workgroups (every launch of layers 2-4) cannot hide behind other
+// workgroups' MFMAs because the workgroups of a round reach their epilogues together.  Here the wave's scale / shift rows are two
+// loads (one channel per lane, handed out by ds_bpermute) and ALL residual pieces of the tile are in flight before the first
+// staged row is read: one latency per tile.  Compile-time HAS_RES keeps the body free of branches, so the compiler's s_waitcnt
+// counts stay exact (a runtime `if (a.res)` around a load makes every later wait a vmcnt(0)).
+// (registers of the residual window: what fits beside the accumulators without costing the kernels a wave per SIMD)
+#ifndef PLAIN_EPI_WINDOW
+#define PLAIN_EPI_WINDOW 8
+#endif
+template <int BM, int BN, int BK, bool HAS_RES>
+__device__ __forceinline__ void igemm_epilogue_plain(const ConvArgs& a, f32x4 (&acc)[BM / 32][BN / 32], float* smem, int m0, int n0, int wave, int lane) {
+  using Cfg = IgemmCfg<BM, BN, BK>;
+  constexpr int FM = Cfg::FM, FN = Cfg::FN;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lg = lane >> 4;
+  float* st = smem + wave * (16 * Cfg::ST_STRIDE);
+  const bool relu = a.relu != 0;
+  // channel n0 + wn*WN + c of this wave's tile: lane c holds its scale / shift (WN = 32: the upper lanes repeat the lower ones)
+  const int cn = n0 + wn * Cfg::WN + (lane & (Cfg::WN - 1));
+  const float scv = a.scale[cn], sfv = a.shift[cn];
+  auto stage = [&](int jn) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if constexpr (FM == 4) {
+        *reinterpret_cast<float4*>(&st[li * Cfg::ST_STRIDE + 16 * lg + 4 * r]) = make_float4(acc[0][jn][r], acc[1][jn][r], acc[2][jn][r], acc[3][jn][r]);
+      } else {
+        *reinterpret_cast<float2*>(&st[li * Cfg::ST_STRIDE + 8 * lg + 2 * r]) = make_float2(acc[0][jn][r], acc[1][jn][r]);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  auto staged = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  if (a.vw == 4) {
+    constexpr int LPR = Cfg::WM / 4, RPI = 64 / LPR, ITS = 16 / RPI;
+    const int rrow = lane / LPR, rcol = (lane % LPR) * 4;
+    const int mm = m0 + wm * Cfg::WM + rcol;
+    const bool mok = mm < a.M;  // M % 4 == 0 here: the group of 4 is all-in or all-out
+    int bb = 0, pp = 0;
+    if (mok) { bb = (int)a.dTHWo.div((unsigned)mm); pp = mm - bb * a.MP; }
+    // this lane's piece (jn, i) = channel nbase + FN * (rrow + RPI * i) + jn, positions pp .. pp + 3 of sample bb: a per-lane pointer
+    // plus a uniform multiple of THWo (lanes past M point at sample 0 and drop what they read)
+    const int nrow = n0 + wn * Cfg::WN + FN * rrow;
+    const float* rp0 = HAS_RES ? a.res + ((size_t)bb * a.Cout + nrow) * a.THWo + pp : nullptr;
+    float* yp0 = a.y + (size_t)bb * a.y_bstride + (size_t)nrow * a.THWo + pp;
+    const unsigned thwo = (unsigned)a.THWo;
+    // residual pieces k = jn * ITS + i through a window of W float4 registers: W loads in flight, piece k + W issued when piece k is used
+    constexpr int NP = FN * ITS, W = PLAIN_EPI_WINDOW / 4;
+    float rv[HAS_RES ? W : 1][4];
+    auto issue = [&](int k) __attribute__((always_inline)) { vec_load<4>(rp0 + (size_t)((unsigned)(FN * RPI * (k % ITS) + k / ITS) * thwo), rv[k % W]); };
+    if constexpr (HAS_RES) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) issue(k);
+    }
+#pragma unroll
+    for (int jn = 0; jn < FN; ++jn) {
+      stage(jn);
+#pragma unroll
+      for (int i = 0; i < ITS; ++i) {
+        const int row = rrow + RPI * i, k = jn * ITS + i;
+        float v[4];
+        vec_load<4>(&st[row * Cfg::ST_STRIDE + rcol], v);
+        const float sc = __shfl(scv, FN * row + jn), sf = __shfl(sfv, FN * row + jn);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * sc + sf;
+        if constexpr (HAS_RES) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += rv[k % W][e];
+          if (k + W < NP) issue(k + W);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = relu ? fmaxf(v[e], 0.f) : v[e];
+        if (mok) vec_store<4>(yp0 + (size_t)((unsigned)(FN * RPI * i + jn) * thwo), v);
+      }
+      staged();
+    }
+    return;
+  }
+  {
+    constexpr int RPI = 64 / Cfg::WM, ITS = 16 / RPI;  // channel rows per read instruction (1 or 2)
+    const int rrow = lane / Cfg::WM, rcol = lane % Cfg::WM;
+    const int mm = m0 + wm * Cfg::WM + rcol;
+    bool mok = mm < a.M;
+    int bb = 0, pp = 0;
+    if (mok) {
+      bb = (int)a.dTHWo.div((unsigned)mm);
+      pp = mm - bb * a.MP;
+      mok = pp < a.THWo;  // (virtually padded rows: see ConvArgs::MP)
+    }
+    if (!mok) bb = pp = 0;  // (these lanes read sample 0 and drop it)
+    const int nrow = n0 + wn * Cfg::WN + FN * rrow;
+    const float* rp0 = HAS_RES ? a.res + ((size_t)bb * a.Cout + nrow) * a.THWo + pp : nullptr;
+    float* yp0 = a.y + (size_t)bb * a.y_bstride + (size_t)nrow * a.THWo + pp;
+    const unsigned thwo = (unsigned)a.THWo;
+    constexpr int NP = FN * ITS, W = PLAIN_EPI_WINDOW;  // (one position per lane: dword pieces)
+    float rv[HAS_RES ? W : 1];
+    auto issue = [&](int k) __attribute__((always_inline)) { rv[k % W] = rp0[(size_t)((unsigned)(FN * RPI * (k % ITS) + k / ITS) * thwo)]; };
+    if constexpr (HAS_RES) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) issue(k);
+    }
+#pragma unroll
+    for (int jn = 0; jn < FN; ++jn) {
+      stage(jn);
+#pragma unroll
+      for (int i = 0; i < ITS; ++i) {
+        const int row = rrow + RPI * i, k = jn * ITS + i;
+        float v = st[row * Cfg::ST_STRIDE + rcol];
+        v = v * __shfl(scv, FN * row + jn) + __shfl(sfv, FN * row + jn);
+        if constexpr (HAS_RES) {
+          v += rv[k % W];
+          if (k + W < NP) issue(k + W);
+        }
+        v = relu ? fmaxf(v, 0.f) : v;
+        if (mok) yp0[(size_t)((unsigned)(FN * RPI * i + jn) * thwo)] = v;
+      }
+      staged();
+    }
+  }
+}
+
 // ---- epilogue shared by both implicit-GEMM kernels -------------------------------------------
 // accumulator element acc[jm][jn][r] of lane (li, lg):
 //   m = m0 + wm*WM + FM*(4*lg + r) + jm,   n = n0 + wn*WN + FN*li + jn
@@ -187,6 +317,14 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[B
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lg = lane >> 4;
   const int b_col = wn * Cfg::WN + FN * li;
+  // (the 128 x 128 tile stays on the path below: its 64 accumulators leave no room for the window at 5 waves per SIMD)
+  if constexpr (BM * BN < 128 * 128) {
+    if (fused && !a.ln_u && !a.y2 && !a.dact && a.relu <= 1) {  // (uniform: kernel arguments)
+      if (a.res) igemm_epilogue_plain<BM, BN, BK, true>(a, acc, smem, m0, n0, wave, lane);
+      else igemm_epilogue_plain<BM, BN, BK, false>(a, acc, smem, m0, n0, wave, lane);
+      return;
+    }
+  }
   float* __restrict__ yout = fused ? a.y : a.y + (size_t)split * a.slab;
   if (a.vw == 4) {
     // Coalesced path (THWo % 4 == 0): each wave transposes its tile through LDS, one fragment
