@@ -176,27 +176,32 @@ __device__ __forceinline__ float act_gelu_grad(float x) {
 }
 __device__ __forceinline__ float act_apply(int code, float v) { return code == 1 ? fmaxf(v, 0.f) : (code == 2 ? act_gelu(v) : v); }
 
-// ---- the plain epilogue: y = act(acc * scale + shift (+ res)), act in {none, ReLU} -- every conv of the I3D plan and the MGFN GEMMs
-// without LayerNorm fold / GELU / second output.  Same arithmetic, LDS transposition and store pattern as igemm_epilogue below;
-// what differs is the order of the memory operations: below, every staged row waits for its scale / shift loads, then for its
-// residual load, then stores -- FN * 16 / RPI rounds of two dependent latencies per tile (8 x 2 for the 128 x 64 tile, 32 x 2 on
-// the unaligned path), which a launch of one or two rounds of workgroups (every launch of layers 2-4) cannot hide behind other
-// workgroups' MFMAs because the workgroups of a round reach their epilogues together.  Here the wave's scale / shift rows are two
-// loads (one channel per lane, handed out by ds_bpermute) and ALL residual pieces of the tile are in flight before the first
-// staged row is read: one latency per tile.  Compile-time HAS_RES keeps the body free of branches, so the compiler's s_waitcnt
-// counts stay exact (a runtime `if (a.res)` around a load makes every later wait a vmcnt(0)).
-// (registers of the residual window: what fits beside the accumulators without costing the kernels a wave per SIMD)
+// ---- the pipelined epilogue: y = act(acc * scale + shift (+ res)) (* GELU'(z)), act in {none, ReLU, GELU (+ the pre-activation as a
+// second output)} -- every conv of the I3D plan and every MGFN GEMM without a LayerNorm fold.  Same arithmetic, LDS transposition
+// and store pattern as igemm_epilogue below; what differs is the order of the memory operations: below, every staged row waits for
+// its scale / shift loads, then for its residual (or z) load, then stores -- FN * 16 / RPI rounds of two dependent latencies per
+// tile (8 x 2 for the 128 x 64 tile, 32 x 2 on the unaligned path), which a launch of one or two rounds of workgroups (every launch
+// of I3D's layers 2-4, the MGFN GEMMs) cannot hide behind other workgroups' MFMAs because the workgroups of a round reach their
+// epilogues together.  Here the wave's scale / shift rows are two loads (one channel per lane, handed out by ds_bpermute) and the
+// residual (or z) pieces of the tile run through a window of PLAIN_EPI_WINDOW registers: that many loads in flight, piece k + W
+// issued when piece k is used.  The operand kind is a template parameter, which keeps the body free of branches around loads, so
+// the compiler's s_waitcnt counts stay exact (a runtime `if (a.res)` around a load makes every later wait a vmcnt(0)).
+// Window size: 8 registers measured = 12 (3 826 / 3 828 clips/s); 16 costs the 6-wave kernels 12-44 bytes of scratch and 2.6 %.
 #ifndef PLAIN_EPI_WINDOW
 #define PLAIN_EPI_WINDOW 8
 #endif
-template <int BM, int BN, int BK, bool HAS_RES>
+enum EpiMode { EM_PLAIN = 0, EM_RES = 1, EM_DACT = 2, EM_GELU = 3 };  // operand read per piece: none / residual / z of GELU'(z); act: ReLU flag / GELU
+
+template <int BM, int BN, int BK, int MODE>
 __device__ __forceinline__ void igemm_epilogue_plain(const ConvArgs& a, f32x4 (&acc)[BM / 32][BN / 32], float* smem, int m0, int n0, int wave, int lane) {
   using Cfg = IgemmCfg<BM, BN, BK>;
   constexpr int FM = Cfg::FM, FN = Cfg::FN;
+  constexpr bool OPERAND = MODE == EM_RES || MODE == EM_DACT;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lg = lane >> 4;
   float* st = smem + wave * (16 * Cfg::ST_STRIDE);
   const bool relu = a.relu != 0;
+  const float* __restrict__ opnd = MODE == EM_RES ? a.res : a.dact;
   // channel n0 + wn*WN + c of this wave's tile: lane c holds its scale / shift (WN = 32: the upper lanes repeat the lower ones)
   const int cn = n0 + wn * Cfg::WN + (lane & (Cfg::WN - 1));
   const float scv = a.scale[cn], sfv = a.shift[cn];
@@ -218,6 +223,16 @@ __device__ __forceinline__ void igemm_epilogue_plain(const ConvArgs& a, f32x4 (&
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
+  // one value through scale / shift, operand and activation (the expressions of igemm_epilogue, in its order)
+  auto finish = [&](float v, float sc, float sf, float op, float& pre) __attribute__((always_inline)) {
+    v = v * sc + sf;
+    if constexpr (MODE == EM_RES) v += op;
+    pre = v;
+    if constexpr (MODE == EM_GELU) v = act_gelu(v);
+    else v = relu ? fmaxf(v, 0.f) : v;
+    if constexpr (MODE == EM_DACT) v *= act_gelu_grad(op);
+    return v;
+  };
   if (a.vw == 4) {
     constexpr int LPR = Cfg::WM / 4, RPI = 64 / LPR, ITS = 16 / RPI;
     const int rrow = lane / LPR, rcol = (lane % LPR) * 4;
@@ -228,14 +243,15 @@ __device__ __forceinline__ void igemm_epilogue_plain(const ConvArgs& a, f32x4 (&
     // this lane's piece (jn, i) = channel nbase + FN * (rrow + RPI * i) + jn, positions pp .. pp + 3 of sample bb: a per-lane pointer
     // plus a uniform multiple of THWo (lanes past M point at sample 0 and drop what they read)
     const int nrow = n0 + wn * Cfg::WN + FN * rrow;
-    const float* rp0 = HAS_RES ? a.res + ((size_t)bb * a.Cout + nrow) * a.THWo + pp : nullptr;
-    float* yp0 = a.y + (size_t)bb * a.y_bstride + (size_t)nrow * a.THWo + pp;
+    const float* rp0 = OPERAND ? opnd + ((size_t)bb * a.Cout + nrow) * a.THWo + pp : nullptr;
+    const size_t yoff = (size_t)bb * a.y_bstride + (size_t)nrow * a.THWo + pp;
+    float* yp0 = a.y + yoff;
     const unsigned thwo = (unsigned)a.THWo;
-    // residual pieces k = jn * ITS + i through a window of W float4 registers: W loads in flight, piece k + W issued when piece k is used
+    // operand pieces k = jn * ITS + i through a window of W float4 registers
     constexpr int NP = FN * ITS, W = PLAIN_EPI_WINDOW / 4;
-    float rv[HAS_RES ? W : 1][4];
+    float rv[OPERAND ? W : 1][4];
     auto issue = [&](int k) __attribute__((always_inline)) { vec_load<4>(rp0 + (size_t)((unsigned)(FN * RPI * (k % ITS) + k / ITS) * thwo), rv[k % W]); };
-    if constexpr (HAS_RES) {
+    if constexpr (OPERAND) {
 #pragma unroll
       for (int k = 0; k < W; ++k) issue(k);
     }
@@ -245,19 +261,19 @@ __device__ __forceinline__ void igemm_epilogue_plain(const ConvArgs& a, f32x4 (&
 #pragma unroll
       for (int i = 0; i < ITS; ++i) {
         const int row = rrow + RPI * i, k = jn * ITS + i;
-        float v[4];
+        float v[4], pre[4];
         vec_load<4>(&st[row * Cfg::ST_STRIDE + rcol], v);
         const float sc = __shfl(scv, FN * row + jn), sf = __shfl(sfv, FN * row + jn);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] * sc + sf;
-        if constexpr (HAS_RES) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += rv[k % W][e];
+        for (int e = 0; e < 4; ++e) v[e] = finish(v[e], sc, sf, OPERAND ? rv[k % W][e] : 0.f, pre[e]);
+        if constexpr (OPERAND) {
           if (k + W < NP) issue(k + W);
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = relu ? fmaxf(v[e], 0.f) : v[e];
-        if (mok) vec_store<4>(yp0 + (size_t)((unsigned)(FN * RPI * i + jn) * thwo), v);
+        const size_t po = (size_t)((unsigned)(FN * RPI * i + jn) * thwo);
+        if constexpr (MODE == EM_GELU) {
+          if (a.y2 && mok) vec_store<4>(a.y2 + yoff + po, pre);
+        }
+        if (mok) vec_store<4>(yp0 + po, v);
       }
       staged();
     }
@@ -276,13 +292,14 @@ __device__ __forceinline__ void igemm_epilogue_plain(const ConvArgs& a, f32x4 (&
     }
     if (!mok) bb = pp = 0;  // (these lanes read sample 0 and drop it)
     const int nrow = n0 + wn * Cfg::WN + FN * rrow;
-    const float* rp0 = HAS_RES ? a.res + ((size_t)bb * a.Cout + nrow) * a.THWo + pp : nullptr;
-    float* yp0 = a.y + (size_t)bb * a.y_bstride + (size_t)nrow * a.THWo + pp;
+    const float* rp0 = OPERAND ? opnd + ((size_t)bb * a.Cout + nrow) * a.THWo + pp : nullptr;
+    const size_t yoff = (size_t)bb * a.y_bstride + (size_t)nrow * a.THWo + pp;
+    float* yp0 = a.y + yoff;
     const unsigned thwo = (unsigned)a.THWo;
     constexpr int NP = FN * ITS, W = PLAIN_EPI_WINDOW;  // (one position per lane: dword pieces)
-    float rv[HAS_RES ? W : 1];
+    float rv[OPERAND ? W : 1];
     auto issue = [&](int k) __attribute__((always_inline)) { rv[k % W] = rp0[(size_t)((unsigned)(FN * RPI * (k % ITS) + k / ITS) * thwo)]; };
-    if constexpr (HAS_RES) {
+    if constexpr (OPERAND) {
 #pragma unroll
       for (int k = 0; k < W; ++k) issue(k);
     }
@@ -292,14 +309,17 @@ __device__ __forceinline__ void igemm_epilogue_plain(const ConvArgs& a, f32x4 (&
 #pragma unroll
       for (int i = 0; i < ITS; ++i) {
         const int row = rrow + RPI * i, k = jn * ITS + i;
+        float pre;
         float v = st[row * Cfg::ST_STRIDE + rcol];
-        v = v * __shfl(scv, FN * row + jn) + __shfl(sfv, FN * row + jn);
-        if constexpr (HAS_RES) {
-          v += rv[k % W];
+        v = finish(v, __shfl(scv, FN * row + jn), __shfl(sfv, FN * row + jn), OPERAND ? rv[k % W] : 0.f, pre);
+        if constexpr (OPERAND) {
           if (k + W < NP) issue(k + W);
         }
-        v = relu ? fmaxf(v, 0.f) : v;
-        if (mok) yp0[(size_t)((unsigned)(FN * RPI * i + jn) * thwo)] = v;
+        const size_t po = (size_t)((unsigned)(FN * RPI * i + jn) * thwo);
+        if constexpr (MODE == EM_GELU) {
+          if (a.y2 && mok) a.y2[yoff + po] = pre;
+        }
+        if (mok) yp0[po] = v;
       }
       staged();
     }
@@ -317,11 +337,16 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[B
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lg = lane >> 4;
   const int b_col = wn * Cfg::WN + FN * li;
-  // (the 128 x 128 tile stays on the path below: its 64 accumulators leave no room for the window at 5 waves per SIMD)
-  if constexpr (BM * BN < 128 * 128) {
-    if (fused && !a.ln_u && !a.y2 && !a.dact && a.relu <= 1) {  // (uniform: kernel arguments)
-      if (a.res) igemm_epilogue_plain<BM, BN, BK, true>(a, acc, smem, m0, n0, wave, lane);
-      else igemm_epilogue_plain<BM, BN, BK, false>(a, acc, smem, m0, n0, wave, lane);
+  if (fused && !a.ln_u) {  // (uniform: kernel arguments)
+    // GELU and GELU' forms: the 128 x 128 tile only (the MGFN FFN GEMMs; 4 waves per SIMD there).  In the 6- and 8-wave kernels
+    // their erf temporaries spill, and scratch in a kernel costs the whole plan more than these forms gain on small layers.
+    if constexpr (BM * BN >= 128 * 128) {
+      if (a.relu == 2 && !a.res && !a.dact) { igemm_epilogue_plain<BM, BN, BK, EM_GELU>(a, acc, smem, m0, n0, wave, lane); return; }
+      if (a.relu <= 1 && !a.y2 && a.dact && !a.res) { igemm_epilogue_plain<BM, BN, BK, EM_DACT>(a, acc, smem, m0, n0, wave, lane); return; }
+    }
+    if (a.relu <= 1 && !a.y2 && !a.dact) {
+      if (a.res) igemm_epilogue_plain<BM, BN, BK, EM_RES>(a, acc, smem, m0, n0, wave, lane);
+      else igemm_epilogue_plain<BM, BN, BK, EM_PLAIN>(a, acc, smem, m0, n0, wave, lane);
       return;
     }
   }
