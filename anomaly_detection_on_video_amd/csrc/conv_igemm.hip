@@ -190,6 +190,9 @@ __device__ __forceinline__ float act_apply(int code, float v) { return code == 1
 #ifndef PLAIN_EPI_WINDOW
 #define PLAIN_EPI_WINDOW 8
 #endif
+#ifndef SPLITK_SUM_BATCH
+#define SPLITK_SUM_BATCH 4
+#endif
 enum EpiMode { EM_PLAIN = 0, EM_RES = 1, EM_DACT = 2, EM_GELU = 3 };  // operand read per piece: none / residual / z of GELU'(z); act: ReLU flag / GELU
 
 template <int BM, int BN, int BK, int MODE>
@@ -873,16 +876,23 @@ __device__ __forceinline__ void brick_epilogue(const ConvArgs& a, f32x4 (&acc)[B
       const int pw = tid % BW, c0 = tid / BW;  // BW = 64 positions, 4 channel groups
       const int ow = bk_w * BW + pw;
       if (ow < a.Wo) {
+        // (the 16 residual values of the pass in flight together: one load latency per pass instead of one per channel)
+        float r0[CH / 4], r1[CH / 4];
+#pragma unroll
+        for (int i = 0; i < CH / 4; ++i) r0[i] = r1[i] = 0.f;
+        if (a.res) {
+          const float* rp = a.res + ((size_t)bk_b * a.Cout + n0 + 2 * c0 + jn) * a.THWo + (size_t)(bk_t * 2) * a.HWo + ow;
+#pragma unroll
+          for (int i = 0; i < CH / 4; ++i) {
+            r0[i] = rp[(size_t)(8 * i) * a.THWo];
+            r1[i] = rp[(size_t)(8 * i) * a.THWo + a.HWo];
+          }
+        }
 #pragma unroll
         for (int i = 0; i < CH / 4; ++i) {
           const int c = c0 + 4 * i;
           const int n = n0 + 2 * c + jn;
-          float v0 = smem[c * RS + pw], v1 = smem[c * RS + 64 + pw];
-          if (a.res) {
-            const size_t o = ((size_t)bk_b * a.Cout + n) * a.THWo + (size_t)(bk_t * 2) * a.HWo + ow;
-            v0 += a.res[o];
-            v1 += a.res[o + a.HWo];
-          }
+          float v0 = smem[c * RS + pw] + r0[i], v1 = smem[c * RS + 64 + pw] + r1[i];
           if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
           a.y[(size_t)bk_b * a.y_bstride + ((size_t)n * a.Tp + bk_t) * a.HWo + ow] = fmaxf(v0, v1);
         }
@@ -1120,8 +1130,8 @@ __device__ __forceinline__ float wave_sum64(float v) {
   return v;
 }
 
-template <int BM, int BN, int BK>
-__device__ __forceinline__ void avg_epilogue(const ConvArgs& a, f32x4 (&acc)[BM / 32][BN / 32], float* smem, int b, int n0, int wave, int lane, int tid) {
+template <int BM, int BN, int BK, bool HAS_RES>
+__device__ __forceinline__ void avg_epilogue_body(const ConvArgs& a, f32x4 (&acc)[BM / 32][BN / 32], float* smem, int b, int n0, int wave, int lane, int tid) {
   using Cfg = IgemmCfg<BM, BN, BK>;
   static_assert(BM == 128 && BN == 64, "one sample per 128-row tile, 2 x 2 waves");
   constexpr int FN = Cfg::FN;
@@ -1131,6 +1141,20 @@ __device__ __forceinline__ void avg_epilogue(const ConvArgs& a, f32x4 (&acc)[BM 
   float* part = smem + Cfg::ST_FLOATS;  // [2 chunks of 64 positions][64 channels]
   const int pp = wm * 64 + lane;        // this lane's position in the read phase
   const bool mok = pp < a.THWo;
+  const bool relu = a.relu != 0;
+  // (as igemm_epilogue_plain: the wave's 32 scale / shift values one per lane, the 32 residual values of a lane through a window of
+  // PLAIN_EPI_WINDOW registers -- the 32 rows below used to wait for a scale / shift load and then a residual load each)
+  const int cn = n0 + wn * Cfg::WN + (lane & (Cfg::WN - 1));
+  const float scv = a.scale[cn], sfv = a.shift[cn];
+  const float* rp0 = HAS_RES ? a.res + ((size_t)b * a.Cout + n0 + wn * Cfg::WN) * a.THWo + (mok ? pp : 0) : nullptr;
+  const unsigned thwo = (unsigned)a.THWo;
+  constexpr int NP = FN * 16, W = PLAIN_EPI_WINDOW;
+  float rv[HAS_RES ? W : 1];
+  auto issue = [&](int k) __attribute__((always_inline)) { rv[k % W] = rp0[(size_t)((unsigned)(FN * (k % 16) + k / 16) * thwo)]; };
+  if constexpr (HAS_RES) {
+#pragma unroll
+    for (int k = 0; k < W; ++k) issue(k);
+  }
 #pragma unroll
   for (int jn = 0; jn < FN; ++jn) {
 #pragma unroll
@@ -1141,14 +1165,14 @@ __device__ __forceinline__ void avg_epilogue(const ConvArgs& a, f32x4 (&acc)[BM 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int row = 0; row < 16; ++row) {
-      const int c = wn * Cfg::WN + FN * row + jn, n = n0 + c;
-      float v = 0.f;
-      if (mok) {
-        v = st[row * Cfg::ST_STRIDE + lane] * a.scale[n] + a.shift[n];
-        if (a.res) v += a.res[((size_t)b * a.Cout + n) * a.THWo + pp];
-        if (a.relu) v = act_apply(a.relu, v);
+      const int c = wn * Cfg::WN + FN * row + jn, k = jn * 16 + row;
+      float v = st[row * Cfg::ST_STRIDE + lane] * __shfl(scv, FN * row + jn) + __shfl(sfv, FN * row + jn);
+      if constexpr (HAS_RES) {
+        v += rv[k % W];
+        if (k + W < NP) issue(k + W);
       }
-      v = wave_sum64(v);
+      v = relu ? fmaxf(v, 0.f) : v;
+      v = wave_sum64(mok ? v : 0.f);
       if (lane == 0) part[wm * 64 + c] = v;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1157,6 +1181,12 @@ __device__ __forceinline__ void avg_epilogue(const ConvArgs& a, f32x4 (&acc)[BM 
   }
   __syncthreads();
   if (tid < 64) a.avg_out[(size_t)b * a.Cout + n0 + tid] = (part[tid] + part[64 + tid]) / (float)a.THWo;
+}
+
+template <int BM, int BN, int BK>
+__device__ __forceinline__ void avg_epilogue(const ConvArgs& a, f32x4 (&acc)[BM / 32][BN / 32], float* smem, int b, int n0, int wave, int lane, int tid) {
+  if (a.res) avg_epilogue_body<BM, BN, BK, true>(a, acc, smem, b, n0, wave, lane, tid);
+  else avg_epilogue_body<BM, BN, BK, false>(a, acc, smem, b, n0, wave, lane, tid);
 }
 
 template <int BM, int BN, int BK, bool CHECK, int NS = 3, int EPI = EPI_STD, bool U8 = false, int AMODE = 0>
@@ -1567,9 +1597,11 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
     // the last arriver: every slice of this tile has been published (write-through, drained before its ticket).  sc1
     // loads bypass this CU's L1 (never refreshed by other CUs' stores); sum in slice order -> run-to-run bit-identical
     // (in batches of G float4 per thread: the sums must not cost the main loop registers -- the occupancy target above
-    // is what keeps the matrix pipe busy -- so at most G loads per lane are in flight, one slice at a time)
+    // is what keeps the matrix pipe busy -- so at most G loads per lane are in flight, one slice at a time.  G = 8 fits the
+    // registers of every plan kernel too and halves the number of load latencies on the last arriver's path; measured on the
+    // stream it changes nothing: 3 826 / 3 841 against 3 834 / 3 844 clips/s, alternating runs on one box)
     const unsigned t0 = (unsigned)(L * a.splits) * TILE_BYTES + (unsigned)tid * 16u;
-    constexpr int NV = FM * FN, G = NV < 4 ? NV : 4;
+    constexpr int NV = FM * FN, G = NV < SPLITK_SUM_BATCH ? NV : SPLITK_SUM_BATCH;
     auto at = [&](int v) -> f32x4& { return acc[v / FN][v % FN]; };
 #pragma unroll
     for (int g0 = 0; g0 < NV; g0 += G) {
@@ -3043,9 +3075,9 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
   Choice c = choose(d, M, g.Kpad);
   if (avg_out != nullptr) {  // conv + global mean in one launch: one sample per 128-row tile of the 2-deep LDS-DMA kernel, unsplit
     ADVHIP_REQUIRE(d->kt == 1 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->ph == 0 && d->pw == 0 &&
-                       g.K == g.Kpad && a.THWo <= 128 && d->Cout % 64 == 0 && ((uintptr_t)x & 15) == 0 && !ln && y_preact == nullptr && dact_z == nullptr,
+                       g.K == g.Kpad && a.THWo <= 128 && d->Cout % 64 == 0 && ((uintptr_t)x & 15) == 0 && !ln && y_preact == nullptr && dact_z == nullptr && a.relu <= 1,
                    "conv3d: avgpool_out needs a 1x1x1 stride-1 conv on <= 128 positions per sample (%d), Cin %% 16 == 0, Cout %% 64 == 0, x 16-byte aligned, "
-                   "no other epilogue operand", a.THWo);
+                   "no other epilogue operand, activation none or ReLU", a.THWo);
     c.algo = ADVHIP_ALGO_DMA2_BASE + ADVHIP_ALGO_IGEMM_128x64;
     c.splits = 1;
   }
