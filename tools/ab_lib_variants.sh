@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library variants on one box: tools/_ab_so.sh OUT name1=path1.so name2=path2.so ...  ("base" = the in-tree library)
+# A/B of library variants on one box: tools/ab_lib_variants.sh OUT name1=path1.so name2=path2.so ...  ("base" = the in-tree library)
 OUT=$1; shift
 mkdir -p $OUT
 SO=anomaly_detection_on_video_amd/csrc/libadvhip.so
