@@ -111,6 +111,28 @@ def test_conv_bn_act_vs_oracle(case, algo):
         assert e < TOL
 
 
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0] in ("l1.conv3", "l4.conv2", "edge.7x7", "edge.odd")], ids=lambda c: c[0])
+@pytest.mark.parametrize("algo", [0, 161, 162, 163, 164, 66, 3], ids=["auto", "dma2_128x128", "dma2_128x64", "dma2_64x64", "dma2_64x128", "dma_128x64", "igemm_64x64"])
+def test_conv_residual_may_be_the_output_buffer(case, algo):
+    """y = act(conv(x) + res) written over `res` itself (the Bottleneck's `out += residual`, src/i3d.py:118-121, done in place): the
+    epilogue keeps several residual pieces in flight before it stores anything, so every piece must have been read by the lane that
+    overwrites it -- the in-place launch equals the out-of-place one bit for bit, on rows of a multiple of 4 positions and on odd ones."""
+    from anomaly_detection_on_video_amd import ops
+
+    name, cin, cout, k, s, p, bthw = case
+    _skip_algo(algo, cout, k)
+    x, wt, g, be, mu, var, res = _conv_case(*case)
+    dev = _dev()
+    pc = ops.pack_conv(wt.to(dev), g.to(dev), be.to(dev), mu.to(dev), var.to(dev), 1e-5, s, p, name=name)
+    xd, rd = x.to(dev), res.to(dev)
+    want = ops.conv3d_bn_act(xd, pc, relu=True, residual=rd, algo=algo, splits=1)
+    buf = rd.clone()
+    got = ops.conv3d_bn_act(xd, pc, relu=True, residual=buf, algo=algo, splits=1, out=buf)
+    torch.cuda.synchronize()
+    assert got.data_ptr() == buf.data_ptr()
+    assert torch.equal(got, want)
+
+
 def test_conv_and_pool_on_channel_slices():
     """x / y as channel slices of wider NCDHW buffers (batch stride > one sample): how layer1.0's downsample branch is
     folded into conv3 -- the pool writes channels [0,64) and conv2 channels [64,128) of one buffer, and a 128-channel
