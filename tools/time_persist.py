@@ -30,7 +30,8 @@ for uname, ci, (cin, t, h, w), use_res in CASES:
         continue
     x = torch.randn((B, cin, t, h, w), device=dev)
     res = torch.randn((B, pc.cout, t, h, w), device=dev) if use_res else None
-    ids = list(_lib.PERSIST_ALGOS)
+    ids = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else list(_lib.PERSIST_ALGOS)  # (any algo ids: e.g. the 3-deep ring family 65..72)
+    ids = [i for i in ids if pc.cout % _lib.algo_tile(i)[1] == 0]
     fns = [lambda: ops.conv3d_bn_act(x, pc, relu=True, residual=res)] + [lambda a=a: ops.conv3d_bn_act(x, pc, relu=True, residual=res, algo=a) for a in ids]
     ts = bench(fns, reps=20, rounds=5)
     flop = 2.0 * B * t * h * w * cin * pc.cout
