@@ -1649,9 +1649,11 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
 //     tile is written after the barrier of its last k-tile and read in the third interval of its successor (nk >= 4).
 // Same operand layout, k order and accumulation chain as conv3d_igemm_dma_kernel (unsplit): bit-identical results.
 // (registers: two 8-wave workgroups per CU for the 128-row tile = 4 waves per SIMD = 128 VGPRs; three for the 64-row one)
+constexpr int PERSIST_MIN_NK = 4;  // k-tiles per output tile the staging hand-over needs (checked by the launcher AND the kernel)
+constexpr int GFX950_XCDS = 8;      // workgroups are dealt round-robin to the XCDs in dispatch order (MI355X: 8 XCDs x 32 CUs)
 template <int BM, int BN, int NS>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8)))
-void conv1x1_persist_kernel(const ConvArgs a) {
+void conv1x1_persist_kernel(const ConvArgs a, const int n_xcd) {
   constexpr int BK = 16;
   using Cfg = IgemmCfg<BM, BN, BK>;
   using D = DmaCfg<BM, BN, BK>;
@@ -1680,11 +1682,13 @@ void conv1x1_persist_kernel(const ConvArgs a) {
   // this workgroup's tiles: XCD x (= blockIdx % 8, the dispatch order) owns a contiguous eighth of the linear tile order
   // L = tile_m * tiles_n + tile_n, workgroup j of the XCD's gridDim / 8 a contiguous part of that
   const int NT = a.tiles_m * a.tiles_n;
-  const int gx = (int)(gridDim.x >> 3), xcd = (int)(blockIdx.x & 7), jx = (int)(blockIdx.x >> 3);
-  const int lo = (int)(((long long)NT * xcd) >> 3), hi = (int)(((long long)NT * (xcd + 1)) >> 3);
+  // (the launcher makes gridDim.x a multiple of n_xcd)
+  const int gx = (int)gridDim.x / n_xcd, xcd = (int)blockIdx.x % n_xcd, jx = (int)blockIdx.x / n_xcd;
+  const int lo = (int)(((long long)NT * xcd) / n_xcd), hi = (int)(((long long)NT * (xcd + 1)) / n_xcd);
   const int t0 = lo + (int)(((long long)(hi - lo) * jx) / gx), t1 = lo + (int)(((long long)(hi - lo) * (jx + 1)) / gx);
   if (t0 >= t1) return;
   const int nk = a.Kpad / BK;
+  if (nk < PERSIST_MIN_NK) return;   // (the launcher refuses such a K; never let a shorter one race the staging area)
   const int total = (t1 - t0) * nk;  // k-tiles of this workgroup, all its output tiles one after the other
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
   const unsigned stg0 = lds0 + (unsigned)RING * 4u;
@@ -3226,19 +3230,20 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
   }
   if (is_persist(c.algo)) {
     // workgroups that stay: `wgs_per_cu` per compute unit (a multiple of 8 in all, at most one per tile), each walking its share of the tiles
-    ADVHIP_REQUIRE(g.Kpad >= 64, "conv3d: the persistent kernels need K >= 64 (four k-tiles per output tile), got %d", g.K);
+    ADVHIP_REQUIRE(g.Kpad >= 16 * PERSIST_MIN_NK, "conv3d: the persistent kernels need K >= %d (%d k-tiles per output tile), got %d", 16 * PERSIST_MIN_NK,
+                   PERSIST_MIN_NK, g.K);
     ADVHIP_REQUIRE(a.a16 != 0 && c.splits == 1 && !ln && dact_z == nullptr,
                    "conv3d: the persistent kernels (algo %d) take unsplit 1x1x1 stride-1 convs on 16-byte aligned rows without the LayerNorm fold / "
                    "GELU-backward operands (k=%d,%d,%d, splits=%d)", c.algo, d->kt, d->kh, d->kw, c.splits);
     const long long nt = (long long)a.tiles_m * a.tiles_n;
     long long g = (long long)persist_wgs_per_cu(c.algo) * device_cus();
     if (g > nt) g = nt;
-    g = g / 8 * 8;
-    if (g < 8) g = 8;
+    g = g / GFX950_XCDS * GFX950_XCDS;
+    if (g < GFX950_XCDS) g = GFX950_XCDS;
     const dim3 pgrid((unsigned)g);
     switch (persist_tile(c.algo)) {
-      case ADVHIP_ALGO_IGEMM_128x64: hipLaunchKernelGGL((conv1x1_persist_kernel<128, 64, 2>), pgrid, dim3(512), 0, st, a); break;
-      default: hipLaunchKernelGGL((conv1x1_persist_kernel<64, 64, 2>), pgrid, dim3(512), 0, st, a); break;
+      case ADVHIP_ALGO_IGEMM_128x64: hipLaunchKernelGGL((conv1x1_persist_kernel<128, 64, 2>), pgrid, dim3(512), 0, st, a, GFX950_XCDS); break;
+      default: hipLaunchKernelGGL((conv1x1_persist_kernel<64, 64, 2>), pgrid, dim3(512), 0, st, a, GFX950_XCDS); break;
     }
     return check_launch("conv3d persistent");
   }

@@ -657,6 +657,210 @@ __global__ __launch_bounds__(256) void glance_attn_bwd_kernel(const float* __res
   }
 }
 
+// ---- GlanceAttention core for ANY T (dim_head = 64): the validation pass scores a whole video, T = n_clips
+// (/root/reference/src/runner.py:42-50 feeds modeling_mgfn.py:107-123 with T = 50..500+).  One workgroup per (32-query tile,
+// sequence, head); key / value tiles of 32 clips run through LDS with an online softmax (running row maximum m, running sum l,
+// the accumulator rescaled by exp(m_old - m_new) per tile): T x T never exists in memory.  lse[i] = m + log(l) (nullable) is
+// what the backward pass needs instead of the T x T softmax.  Same thread -> element maps as the T = 32 kernel above.
+constexpr float GA_NEG = -3.0e38f;  // "minus infinity" that stays finite under subtraction
+
+__device__ __forceinline__ void ga_load_tile(float (*dst)[GA_T + 1], const float* __restrict__ src, long long row0, long long N, long long col0,
+                                             int t_base, int T, int tid) {
+  for (int e = tid; e < GA_D * GA_T; e += 256) {
+    const int d = e / GA_T, t = e % GA_T, tt = t_base + t;
+    dst[d][t] = tt < T ? src[(row0 + d) * N + col0 + tt] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void glance_attn_fwd_anyt_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ lse,
+                                                                   int inner, int heads, int T, long long N, float scale, int bh0) {
+  __shared__ float q[GA_D][GA_T + 1], k[GA_D][GA_T + 1], v[GA_D][GA_T + 1], p[GA_T][GA_T + 1], alpha_s[GA_T], l_s[GA_T];
+  const int bh = bh0 + blockIdx.y, b = bh / heads, h = bh % heads, tid = threadIdx.x;
+  const int i_base = blockIdx.x * GA_T;
+  const long long col0 = (long long)b * T, row0 = (long long)h * GA_D;
+  ga_load_tile(q, qkv, row0, N, col0, i_base, T, tid);
+  const int i = tid >> 3, j0 = (tid & 7) * 4;   // sim: row i, columns j0 .. j0 + 3
+  const int d2 = tid >> 2, i0 = (tid & 3) * 8;  // out: channel d2, queries i0 .. i0 + 7
+  float m = GA_NEG, l = 0.f, o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+  for (int jb = 0; jb < T; jb += GA_T) {
+    __syncthreads();  // (the previous tile's readers of k, v, p, alpha_s are done; first pass: q is complete)
+    ga_load_tile(k, qkv, inner + row0, N, col0, jb, T, tid);
+    ga_load_tile(v, qkv, 2ll * inner + row0, N, col0, jb, T, tid);
+    __syncthreads();
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < GA_D; ++d) {
+      const float qi = q[d][i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += qi * k[d][j0 + e];
+    }
+    float mx = GA_NEG;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s[e] = (jb + j0 + e < T) ? s[e] * scale : GA_NEG;
+      mx = fmaxf(mx, s[e]);
+    }
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const float m_new = fmaxf(m, mx);  // (finite from the first tile on: key jb is always a real one)
+    const float a = expf(m - m_new);
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s[e] = (jb + j0 + e < T) ? expf(s[e] - m_new) : 0.f;
+      sum += s[e];
+      p[i][j0 + e] = s[e];
+    }
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    l = l * a + sum;
+    m = m_new;
+    if ((tid & 7) == 0) alpha_s[i] = a;
+    __syncthreads();
+    float al[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { al[e] = alpha_s[i0 + e]; o[e] *= al[e]; }
+    for (int j = 0; j < GA_T; ++j) {
+      const float vj = v[d2][j];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += vj * p[i0 + e][j];
+    }
+  }
+  if ((tid & 7) == 0) {
+    l_s[i] = l;
+    if (lse != nullptr && i_base + i < T) lse[(long long)bh * T + i_base + i] = m + logf(l);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (i_base + i0 + e < T) out[(row0 + d2) * N + col0 + i_base + i0 + e] = o[e] / l_s[i0 + e];
+}
+
+// backward for any T from dout, qkv, out and lse: p[i][j] = exp(scale q_i.k_j - lse[i]) is recomputed tile by tile;
+//   D[i] = sum_d dout[d][i] out[d][i];  dp = dout^T v;  ds = p (dp - D) scale;
+//   blockIdx.z = 0: dq[d][i] = sum_j ds[i][j] k[d][j] for one query tile (loop over the key tiles);
+//   blockIdx.z = 1: dk[d][j] = sum_i ds[i][j] q[d][i], dv[d][j] = sum_i dout[d][i] p[i][j] for one key tile (loop over the query tiles).
+// Every output element is written by exactly one thread, sums in tile order: deterministic.
+__global__ __launch_bounds__(256) void glance_attn_bwd_anyt_kernel(const float* __restrict__ dout, const float* __restrict__ qkv,
+                                                                   const float* __restrict__ out, const float* __restrict__ lse,
+                                                                   float* __restrict__ dqkv, int inner, int heads, int T, long long N, float scale, int bh0) {
+  __shared__ float q[GA_D][GA_T + 1], k[GA_D][GA_T + 1], v[GA_D][GA_T + 1], g[GA_D][GA_T + 1], go[GA_D][GA_T + 1];
+  __shared__ float p[GA_T][GA_T + 1], ds[GA_T][GA_T + 1], D_s[GA_T], L_s[GA_T];
+  const int bh = bh0 + blockIdx.y, b = bh / heads, h = bh % heads, tid = threadIdx.x;
+  const bool role_q = blockIdx.z == 0;
+  const int own = blockIdx.x * GA_T;  // the query tile (role_q) or the key tile this workgroup owns
+  const long long col0 = (long long)b * T, row0 = (long long)h * GA_D;
+  const int i = tid >> 3, j0 = (tid & 7) * 4;
+  const int d2 = tid >> 2, t0 = (tid & 3) * 8;
+  float acc0[8], acc1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc0[e] = acc1[e] = 0.f;
+  if (!role_q) {
+    ga_load_tile(k, qkv, inner + row0, N, col0, own, T, tid);
+    ga_load_tile(v, qkv, 2ll * inner + row0, N, col0, own, T, tid);
+  }
+  for (int ob = 0; ob < T; ob += GA_T) {
+    const int ib = role_q ? own : ob, jb = role_q ? ob : own;
+    __syncthreads();
+    if (role_q) {
+      ga_load_tile(k, qkv, inner + row0, N, col0, jb, T, tid);
+      ga_load_tile(v, qkv, 2ll * inner + row0, N, col0, jb, T, tid);
+    }
+    if (!role_q || ob == 0) {  // the query-side tiles: q, dout, dout * out, lse
+      ga_load_tile(q, qkv, row0, N, col0, ib, T, tid);
+      for (int e = tid; e < GA_D * GA_T; e += 256) {
+        const int d = e / GA_T, t = e % GA_T, tt = ib + t;
+        const long long o = (row0 + d) * N + col0 + tt;
+        const float gv = tt < T ? dout[o] : 0.f;
+        g[d][t] = gv;
+        go[d][t] = tt < T ? gv * out[o] : 0.f;
+      }
+      if (tid < GA_T) L_s[tid] = ib + tid < T ? lse[(long long)bh * T + ib + tid] : 0.f;
+    }
+    __syncthreads();
+    if ((!role_q || ob == 0) && tid < GA_T) {
+      float dsum = 0.f;
+      for (int d = 0; d < GA_D; ++d) dsum += go[d][tid];
+      D_s[tid] = dsum;
+    }
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, dp[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < GA_D; ++d) {
+      const float qi = q[d][i], gi = g[d][i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s[e] += qi * k[d][j0 + e];
+        dp[e] += gi * v[d][j0 + e];
+      }
+    }
+    __syncthreads();  // D_s
+    const float Li = L_s[i], Di = D_s[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float pv = (jb + j0 + e < T && ib + i < T) ? expf(s[e] * scale - Li) : 0.f;
+      p[i][j0 + e] = pv;
+      ds[i][j0 + e] = pv * (dp[e] - Di) * scale;
+    }
+    __syncthreads();
+    if (role_q) {
+      for (int r = 0; r < GA_T; ++r) {
+        const float kr = k[d2][r];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc0[e] += ds[t0 + e][r] * kr;  // dq: i = t0 + e, j = r
+      }
+    } else {
+      for (int r = 0; r < GA_T; ++r) {
+        const float gr = g[d2][r], qr = q[d2][r];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          acc0[e] += ds[r][t0 + e] * qr;  // dk: i = r, j = t0 + e
+          acc1[e] += gr * p[r][t0 + e];   // dv
+        }
+      }
+    }
+  }
+  const long long o = (row0 + d2) * N + col0 + own + t0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (own + t0 + e >= T) break;
+    if (role_q) {
+      dqkv[o + e] = acc0[e];
+    } else {
+      dqkv[o + (long long)inner * N + e] = acc0[e];
+      dqkv[o + 2ll * inner * N + e] = acc1[e];
+    }
+  }
+}
+
+
+// ---- a per-input-channel affine map folded into the 1x1 layer that follows it ------------------------------------------------
+// W (O, C), the map x -> mul[c] * x[c] + add[c] in front of it:  W (mul . x + add) = (W diag(mul)) x + W add.
+//   Wf[o][c] = W[o][c] * mul[c];  bias_f[o] = bias[o] + sum_c W[o][c] * add[c];  rowsum[o] = sum_c Wf[o][c] (nullable)
+// Users: eval-mode BatchNorm1d in front of FocusAttention.to_v (modeling_mgfn.py:162, 173-174; mul / add from advhip_bn_fold_f32) and
+// the channel LayerNorm in front of MGFNFeedForward.in_conv at inference (mul = g, add = b, rowsum = the mean term's coefficient).
+// One wave per output row, lanes along c, xor-butterfly sums: operand-build time only (once per set of weights).
+__global__ __launch_bounds__(64) void fold_affine_kernel(const float* __restrict__ W, const float* __restrict__ mul, const float* __restrict__ add,
+                                                         const float* __restrict__ bias, float* __restrict__ Wf, float* __restrict__ bias_f,
+                                                         float* __restrict__ rowsum, int Cc) {
+  const int o = blockIdx.x, lane = threadIdx.x;
+  float sa = 0.f, sw = 0.f;
+  for (int c = lane; c < Cc; c += 64) {
+    const float w = W[(size_t)o * Cc + c];
+    const float wf = w * mul[c];
+    Wf[(size_t)o * Cc + c] = wf;
+    sw += wf;
+    if (add != nullptr) sa += w * add[c];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    sa += __shfl_xor(sa, off, 64);
+    sw += __shfl_xor(sw, off, 64);
+  }
+  if (lane == 0) {
+    bias_f[o] = (bias != nullptr ? bias[o] : 0.f) + sa;
+    if (rowsum != nullptr) rowsum[o] = sw;
+  }
+}
 
 // ---- every GEMM weight of a training step re-packed in ONE launch -------------------------------------------------------
 // A differentiated forward needs the packed image of each (just updated) parameter: 42 forward operands and 8 transposed-conv
@@ -904,6 +1108,41 @@ extern "C" int advhip_glance_attention_bwd_f32(const float* dout, const float* q
   hipLaunchKernelGGL(glance_attn_bwd_kernel, dim3((unsigned)(B * heads)), dim3(256), 0, (hipStream_t)stream, dout, qkv, p, dqkv, heads * GA_D, heads,
                      (long long)B * T, scale);
   return check_launch("glance_attention_bwd");
+}
+
+extern "C" int advhip_glance_attention_fwd_anyt_f32(const float* qkv, float* out, float* lse, int32_t heads, int64_t B, int32_t T, int32_t dim_head,
+                                                    float scale, void* stream) {
+  ADVHIP_REQUIRE(qkv && out && heads > 0 && B > 0 && T > 0, "glance_attention_fwd_anyt: bad arguments");
+  ADVHIP_REQUIRE(dim_head == GA_D, "glance_attention_anyt: dim_head = %d (the kernel is built for %d)", dim_head, GA_D);
+  ADVHIP_REQUIRE(B * heads < (1ll << 31), "glance_attention_anyt: too many (sequence, head) pairs");
+  const unsigned tiles = (unsigned)((T + GA_T - 1) / GA_T);
+  for (long long bh0 = 0; bh0 < B * heads; bh0 += 32768) {  // (grid.y is 16 bits wide)
+    const unsigned ny = (unsigned)std::min<long long>(32768, B * heads - bh0);
+    hipLaunchKernelGGL(glance_attn_fwd_anyt_kernel, dim3(tiles, ny), dim3(256), 0, (hipStream_t)stream, qkv, out, lse, heads * GA_D, heads, T,
+                       (long long)B * T, scale, (int)bh0);
+  }
+  return check_launch("glance_attention_fwd_anyt");
+}
+
+extern "C" int advhip_glance_attention_bwd_anyt_f32(const float* dout, const float* qkv, const float* out, const float* lse, float* dqkv, int32_t heads,
+                                                    int64_t B, int32_t T, int32_t dim_head, float scale, void* stream) {
+  ADVHIP_REQUIRE(dout && qkv && out && lse && dqkv && heads > 0 && B > 0 && T > 0, "glance_attention_bwd_anyt: bad arguments");
+  ADVHIP_REQUIRE(dim_head == GA_D, "glance_attention_anyt: dim_head = %d (the kernel is built for %d)", dim_head, GA_D);
+  ADVHIP_REQUIRE(B * heads < (1ll << 31), "glance_attention_anyt: too many (sequence, head) pairs");
+  const unsigned tiles = (unsigned)((T + GA_T - 1) / GA_T);
+  for (long long bh0 = 0; bh0 < B * heads; bh0 += 32768) {
+    const unsigned ny = (unsigned)std::min<long long>(32768, B * heads - bh0);
+    hipLaunchKernelGGL(glance_attn_bwd_anyt_kernel, dim3(tiles, ny, 2), dim3(256), 0, (hipStream_t)stream, dout, qkv, out, lse, dqkv, heads * GA_D, heads,
+                       T, (long long)B * T, scale, (int)bh0);
+  }
+  return check_launch("glance_attention_bwd_anyt");
+}
+
+extern "C" int advhip_fold_affine_f32(const float* W, const float* mul, const float* add, const float* bias, float* Wf, float* bias_f, float* rowsum,
+                                      int32_t O, int32_t C, void* stream) {
+  ADVHIP_REQUIRE(W && mul && Wf && bias_f && O > 0 && C > 0, "fold_affine: bad arguments");
+  hipLaunchKernelGGL(fold_affine_kernel, dim3((unsigned)O), dim3(64), 0, (hipStream_t)stream, W, mul, add, bias, Wf, bias_f, rowsum, C);
+  return check_launch("fold_affine");
 }
 
 extern "C" int64_t advhip_head_ln_fc_partial_rows(int64_t N) { return (N + LN_COLS - 1) / LN_COLS; }

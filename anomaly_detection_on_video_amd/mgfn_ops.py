@@ -748,34 +748,53 @@ class _FocusAttnBlockCN(torch.autograd.Function):
 
 class _GlanceAttnCore(torch.autograd.Function):
     """out = v softmax(scale q^T k)^T per (sequence, head) on (C, B, T) activations: GlanceAttention between its two 1x1 convs
-    (modeling_mgfn.py:113-122) as one launch forward, one backward (csrc/mgfn.hip: T = 32, dim_head = 64)."""
+    (modeling_mgfn.py:113-122) as one launch forward, one backward (csrc/mgfn.hip).  T = 32 (every training batch: the runner
+    feeds 32-segment videos): the whole (sequence, head) problem in LDS, the softmax kept for the backward pass.  Any other T (the
+    validation pass over a whole video, runner.py:42-50): 32-key tiles with an online softmax, the rows' log-sum-exp kept instead
+    of the T x T softmax, the backward pass recomputing it tile by tile."""
 
     @staticmethod
     def forward(ctx, qkv, heads, dim_head, scale):
         _lib.require_gpu(qkv)
         c3, b, t = qkv.shape
         inner = c3 // 3
+        lib = _lib.load()
         out = torch.empty((inner, b, t), device=qkv.device, dtype=torch.float32)
-        p = torch.empty((b, heads, t, t), device=qkv.device, dtype=torch.float32)
-        check(_lib.load().advhip_glance_attention_fwd_f32(ptr(qkv), ptr(out), ptr(p), heads, b, t, dim_head, C.c_float(scale), stream(qkv)),
-              "glance_attention_fwd")
-        ctx.save_for_backward(qkv, p)
+        need = any(ctx.needs_input_grad)
+        if t == 32:
+            p = torch.empty((b, heads, t, t), device=qkv.device, dtype=torch.float32)
+            check(lib.advhip_glance_attention_fwd_f32(ptr(qkv), ptr(out), ptr(p), heads, b, t, dim_head, C.c_float(scale), stream(qkv)),
+                  "glance_attention_fwd")
+            ctx.save_for_backward(qkv, p)
+        else:
+            lse = torch.empty((b, heads, t), device=qkv.device, dtype=torch.float32) if need else None
+            check(lib.advhip_glance_attention_fwd_anyt_f32(ptr(qkv), ptr(out), ptr(lse), heads, b, t, dim_head, C.c_float(scale), stream(qkv)),
+                  "glance_attention_fwd_anyt")
+            if need:
+                ctx.save_for_backward(qkv, out, lse)
         ctx.args = (heads, dim_head, scale)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, p = ctx.saved_tensors
         heads, dim_head, scale = ctx.args
+        qkv = ctx.saved_tensors[0]
         _, b, t = qkv.shape
         dqkv = torch.empty_like(qkv)
-        check(_lib.load().advhip_glance_attention_bwd_f32(ptr(dout.contiguous()), ptr(qkv), ptr(p), ptr(dqkv), heads, b, t, dim_head, C.c_float(scale),
-                                                          stream(qkv)), "glance_attention_bwd")
+        lib = _lib.load()
+        if t == 32:
+            p = ctx.saved_tensors[1]
+            check(lib.advhip_glance_attention_bwd_f32(ptr(dout.contiguous()), ptr(qkv), ptr(p), ptr(dqkv), heads, b, t, dim_head, C.c_float(scale),
+                                                      stream(qkv)), "glance_attention_bwd")
+        else:
+            _qkv, out, lse = ctx.saved_tensors
+            check(lib.advhip_glance_attention_bwd_anyt_f32(ptr(dout.contiguous()), ptr(qkv), ptr(out), ptr(lse), ptr(dqkv), heads, b, t, dim_head,
+                                                           C.c_float(scale), stream(qkv)), "glance_attention_bwd_anyt")
         return dqkv, None, None, None
 
 
 def glance_attention_ok(qkv: torch.Tensor, heads: int, dim_head: int) -> bool:
-    return fused_ok(qkv) and qkv.is_contiguous() and qkv.shape[2] == 32 and dim_head == 64 and qkv.shape[0] == 3 * heads * dim_head
+    return fused_ok(qkv) and qkv.is_contiguous() and qkv.shape[2] >= 1 and dim_head == 64 and qkv.shape[0] == 3 * heads * dim_head
 
 
 def glance_attention_core(qkv: torch.Tensor, heads: int, dim_head: int, scale: float) -> torch.Tensor:
@@ -867,6 +886,32 @@ def ffn_cn(xh: torch.Tensor, x_res: torch.Tensor, in_conv: torch.nn.Conv1d, out_
 _FOLDED: Dict[int, Tuple] = {}
 
 
+def fold_affine(weight: torch.Tensor, mul: torch.Tensor, add: Optional[torch.Tensor], bias: Optional[torch.Tensor], want_rowsum: bool = False):
+    """The per-channel affine map x -> mul x + add folded into the 1x1 layer (weight (O, C[, 1]), bias) behind it: (W diag(mul)
+    packed as the kernels' [C][O] operand, bias + W add, row sums of W diag(mul) or None) -- one HIP launch + the pack
+    (include/advhip.h: advhip_fold_affine_f32); operand-build time, cached by the callers."""
+    o, c = weight.shape[0], weight.shape[1]
+    w2 = weight.detach().reshape(o, c)
+    _lib.require_gpu(w2, mul, add, bias)
+    wf = torch.empty((o, c, 1), device=w2.device, dtype=torch.float32)
+    bf = torch.empty((o,), device=w2.device, dtype=torch.float32)
+    rs = torch.empty_like(bf) if want_rowsum else None
+    check(_lib.load().advhip_fold_affine_f32(ptr(w2), ptr(mul), ptr(add), ptr(bias), ptr(wf), ptr(bf), ptr(rs), o, c, stream(w2)), "fold_affine")
+    return pack_kc(wf), bf, rs
+
+
+def _folded(owner, params, build):
+    """Operands derived from `params`, cached on id(owner) until one of them changes (data_ptr / version / the cache epoch)."""
+    stamp = tuple((p.data_ptr(), p._version) for p in params) + (_EPOCH,)
+    hit = _FOLDED.get(id(owner))
+    if hit is None or hit[0]() is not owner or hit[1] != stamp:
+        if len(_FOLDED) > 256:
+            for k in [k for k, v in _FOLDED.items() if v[0]() is None]:
+                del _FOLDED[k]
+        hit = _FOLDED[id(owner)] = (weakref.ref(owner), stamp) + tuple(build())
+    return hit[2:]
+
+
 @torch.no_grad()
 def ffn_cn_folded_ln(x: torch.Tensor, norm, in_conv: torch.nn.Conv1d, out_conv: torch.nn.Conv1d) -> torch.Tensor:
     """Inference form of `ffn(x) + x` with the channel LayerNorm folded into the first GEMM: W1.LN(x) = (W1.diag(g)) x_raw
@@ -874,21 +919,34 @@ def ffn_cn_folded_ln(x: torch.Tensor, norm, in_conv: torch.nn.Conv1d, out_conv: 
     The folded operands are cached until one of the four parameters changes."""
     x = x.contiguous()
     hid, dim = in_conv.weight.shape[0], in_conv.weight.shape[1]
-    params = (in_conv.weight, in_conv.bias, norm.g, norm.b)
-    stamp = tuple((p.data_ptr(), p._version) for p in params) + (_EPOCH,)
-    hit = _FOLDED.get(id(in_conv))
-    if hit is None or hit[0]() is not in_conv or hit[1] != stamp:
-        if len(_FOLDED) > 256:
-            for k in [k for k, v in _FOLDED.items() if v[0]() is None]:
-                del _FOLDED[k]
-        w1 = in_conv.weight.view(hid, dim)
-        wg = w1 * norm.g.view(1, dim)
-        hit = _FOLDED[id(in_conv)] = (weakref.ref(in_conv), stamp, pack_kc(wg.view(hid, dim, 1)),
-                                      (in_conv.bias + w1 @ norm.b.view(dim)).contiguous(), wg.sum(1).contiguous())
-    _, _, wg_packed, shift, u = hit
+    wg_packed, shift, u = _folded(in_conv, (in_conv.weight, in_conv.bias, norm.g, norm.b),
+                                  lambda: fold_affine(in_conv.weight, norm.g.detach().reshape(dim).contiguous(), norm.b.detach().reshape(dim).contiguous(),
+                                                      in_conv.bias.detach(), want_rowsum=True))
     mu, rs = chan_stats(x, norm.eps)
     h = conv_cn(x, wg_packed, hid, 1, shift=shift, act=ACT_GELU, ln=(u, mu, rs))
     return conv_cn(h, pack_kc_cached(out_conv.weight), dim, 1, shift=out_conv.bias, residual=x)
+
+
+def bn_eval_fold_ok(x: torch.Tensor, bn: torch.nn.BatchNorm1d, to_v: torch.nn.Conv1d) -> bool:
+    return (not torch.is_grad_enabled() and not bn.training and bn.running_mean is not None and bn.affine and fused_ok(x)
+            and to_v.weight.shape[2] == 1 and eligible(to_v.weight.shape[1], to_v.weight.shape[0], x) and _on_current_device(to_v.weight))
+
+
+@torch.no_grad()
+def to_v_folded_bn(x: torch.Tensor, bn: torch.nn.BatchNorm1d, to_v: torch.nn.Conv1d) -> torch.Tensor:
+    """to_v(BatchNorm1d_eval(x)) as ONE GEMM launch (modeling_mgfn.py:162, 173-174): eval-mode BN is the affine map x -> s x + t,
+    s = gamma / sqrt(running_var + eps), t = beta - running_mean s, so to_v(BN(x)) = (Wv diag(s)) x + Wv t -- the folded operand
+    and bias are built once per set of weights (advhip_bn_fold_f32 + advhip_fold_affine_f32) and cached."""
+    inner = to_v.weight.shape[0]
+
+    def build():
+        scale, shift = ops.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+        wp, bf, _ = fold_affine(to_v.weight, scale, shift, to_v.bias.detach() if to_v.bias is not None else None)
+        return wp, bf
+
+    params = (to_v.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var) + ((to_v.bias,) if to_v.bias is not None else ())
+    wp, bf = _folded(to_v, params, build)
+    return conv_cn(x.contiguous(), wp, inner, 1, shift=bf)
 
 
 # ---- fused element-wise layers (csrc/mgfn.hip) -------------------------------------------------------------------------

@@ -5,8 +5,8 @@ Drop-in for `/root/reference/src/models/mgfn/modeling_mgfn.py`: same class names
 output dataclass fields, `force_split` property and state-dict keys (145 entries).
 
 What runs where
-  * backbone (amplifier, Glance/Focus blocks: Conv1d / attention / GELU; needs autograd): stock
-    PyTorch-ROCm ops -- plumbing, as SURVEY.md K7/K8 allows;
+  * backbone (amplifier, Glance/Focus blocks: Conv1d / attention / GELU, with autograd): the fp32-MFMA GEMM kernels and fused
+    norm / attention / depth-wise-conv launches of csrc/conv_igemm.hip + csrc/mgfn.hip through `mgfn_ops` (see "Body layout" below);
   * the MIL head `magnitude_selection_and_score_prediction` (modeling_mgfn.py:302-374) and the
     four loss terms (loss/base.py, loss/mgfn.py): hand-written wavefront-shuffle HIP kernels with
     custom backward (`mil_ops.py`; csrc/mil.hip, csrc/loss.hip).
@@ -62,19 +62,20 @@ else:  # pragma: no cover
 
 
 # ------------------------------------------------------------------------------------------------
-# Body layout.  The reference feeds (B, C, T) tensors through nn.Conv1d.  On ROCm that goes to
-# MIOpen, whose fp32 Conv1d *backward* for these shapes picks a Winograd kernel at ~9 ms per call
-# (173 of a 200 ms training step, rocprofv3 trace in profiles/).  Every convolution of the scorer is
-# a GEMM over channels (k = 1) or over (tap, channel) (k = 3), so the body below keeps activations
-# as (C, B, T) -- channels outermost -- and runs all of them as plain 2-D matmuls W @ X[C, B*T]
-# (rocBLAS fp32 MFMA, forward and backward), with no layout copies between layers.  The nn.Conv1d /
-# nn.BatchNorm1d children remain the parameter holders (reference state-dict keys); their own
-# forward is not used.
+# Body layout.  The reference feeds (B, C, T) tensors through nn.Conv1d.  Every convolution of the scorer is a GEMM over channels
+# (k = 1) or over (tap, channel) (k = 3), so the body keeps activations as (C, B, T) -- channels outermost, N = B*T positions
+# contiguous -- and every GEMM-shaped layer is Y[o, n] = W[o, c] X[c, n] with X in exactly the LDS-DMA conv kernel's A layout: no
+# layout copies between layers.  The nn.Conv1d / nn.BatchNorm1d children remain the parameter holders (the reference's state-dict
+# keys); their own forward is not used.
 #
-# Layers with >= 128 channels on both sides (stages 1 and 2: 97 % of the scorer's MACs) do not go to rocBLAS but to the
-# hand-written fp32-MFMA kernels through `mgfn_ops` (forward AND backward: the LDS-DMA conv kernel as a GEMM with bias /
-# GELU / residual / LayerNorm-fold / GELU-backward epilogues, advhip_gemm_nt_f32 for the weight gradients); the stage-0
-# layers (64 channels), the 2049-channel amplifier and the attention einsums stay on the torch ops below.
+# Every layer of the default architecture runs on the hand-written fp32-MFMA kernels through `mgfn_ops`, forward AND backward, at
+# any T: the conv kernel as a GEMM with bias / GELU / residual / LayerNorm-fold / GELU-backward epilogues, advhip_gemm_nt_f32 for the
+# weight gradients, the 2048 -> 64 token conv on the input rows as stored (_TokenTaps), GlanceAttention's core as one launch (T = 32:
+# everything in LDS; any other T: key tiles + online softmax), eval-mode BatchNorm1d folded into to_v's operand, the norms / the
+# depth-wise conv / the head as single fused launches.  The torch expressions below (`_pointwise_torch`, `_conv_k_torch`, the einsum
+# attention, `var_mean` norms) remain only for layers outside the kernels' shape rules (mgfn_ops.eligible: channel counts that are
+# not multiples of 64 / 32, dim_head != 64, B*T % 16 != 0 with autograd, tensors off the current device, eval-mode BatchNorm with
+# autograd); each announces itself through `mgfn_ops.torch_path`, which raises under ADV_MGFN_STRICT=1 (tests/test_hip_strict.py).
 # ------------------------------------------------------------------------------------------------
 def _hip(conv: nn.Conv1d, x: torch.Tensor) -> bool:
     return conv.weight.shape[2] in (1, 3) and mgfn_ops.eligible(conv.weight.shape[1], conv.weight.shape[0], x)
@@ -156,6 +157,7 @@ class MGFNFeedForward(nn.Module):
             elif residual is x and mgfn_ops.fused_ok(x) and self.in_conv.bias is not None and self.out_conv.bias is not None:
                 return mgfn_ops.ffn_block_cn(x, self.layer_norm, self.in_conv, self.out_conv)  # LN + FFN + skip: one autograd node
             return mgfn_ops.ffn_cn(self.layer_norm(x), residual, self.in_conv, self.out_conv)
+        mgfn_ops.torch_path(x, "FFN off the fused GEMM pair (channel rules, no residual, or dropout > 0 in training)")
         y = _pointwise(self.out_conv, self.dropout(self.gelu(_pointwise(self.in_conv, self.layer_norm(x)))))
         return y if residual is None else y + residual
 
@@ -193,16 +195,19 @@ class MGFNFeatureAmplifier(nn.Module):
         conv = self.to_tokens
         o, c, k = conv.weight.shape
         wt = conv.weight.permute(2, 0, 1).reshape(k * o, c)              # the k tap matrices, stacked
-        if rows is not None and rows.shape[1] == c + 1 and mgfn_ops.fused_ok(x) and mgfn_ops.token_taps_ok(wt, rows.contiguous()):
+        rows = rows.contiguous() if rows is not None else None
+        if rows is not None and rows.shape[1] == c + 1 and mgfn_ops.fused_ok(x) and mgfn_ops.token_taps_ok(wt, rows):
             # (B*T, C + 1) rows read in place: advhip_gemm_nt_f32 forward, one conv launch on the same rows for the weight gradient
-            z = mgfn_ops.token_taps(wt, rows.contiguous()).view(k, o, b, t)
+            z = mgfn_ops.token_taps(wt, rows).view(k, o, b, t)
         else:
+            mgfn_ops.torch_path(x, "token conv tap GEMM (channels % 16 != 0, taps x dims[0] % 64 != 0, or an input that carries a gradient)")
             xv = x[:c].reshape(c, b * t)                                  # (C, B*T) view of the (B*T, C+1) rows: strides (1, C+1)
             z = torch.matmul(wt, xv).view(k, o, b, t)
         mag = x[c:]
         if k == 3 and mgfn_ops.amp_combine_ok(z, conv, self.to_mag, mag):
             # the shifted add, the bias AND mag_ratio * to_mag(magnitude): one HIP launch forward, one backward -> (tokens, True)
             return mgfn_ops.amp_combine(z, conv, self.to_mag, mag, self.mag_ratio), True
+        mgfn_ops.torch_path(x, "token conv tap sum (k != 3, a conv without bias, or a magnitude channel that is not a view of the input rows)")
         zp = F.pad(z, (k // 2, k // 2))
         y = zp[0, :, :, 0:t]
         for j in range(1, k):
@@ -226,7 +231,7 @@ class GlanceAttention(nn.Module):
         qkv = _pointwise(self.to_qkv, self.norm(x))
         if mgfn_ops.glance_attention_ok(qkv, self.heads, self.dim_head):  # scale, sim, softmax, v attn^T, layout: one HIP launch
             return _pointwise(self.to_out, mgfn_ops.glance_attention_core(qkv, self.heads, self.dim_head, self.scale), residual)
-        mgfn_ops.torch_path(x, "Glance attention core (T != 32 or dim_head != 64)")
+        mgfn_ops.torch_path(x, "Glance attention core (dim_head != 64)")
         qkv = qkv.view(3, self.heads, self.dim_head, b, n)
         q, k, v = (t.permute(2, 0, 1, 3) for t in qkv.unbind(0))  # (b, h, d, n)
         sim = torch.matmul((q * self.scale).transpose(-1, -2), k)  # (b, h, i, j)
@@ -258,6 +263,7 @@ class FocusAttention(nn.Module):
                     bn.running_var.mul_(1 - mom).add_(var * (n / max(n - 1, 1)), alpha=mom)
                     bn.num_batches_tracked += 1
             return y
+        mgfn_ops.torch_path(x, "BatchNorm1d (batch statistics off the fused kernel, or running statistics with autograd)")
         if bn.training:
             var, mean = torch.var_mean(x, dim=(1, 2), unbiased=False)
             if bn.track_running_stats:
@@ -280,7 +286,10 @@ class FocusAttention(nn.Module):
                 and self.to_out.bias is not None and self.rel_pos.weight.shape[-1] in (3, 5)):
             # BN + to_v + rel_pos + to_out + skip as one autograd node (mgfn_ops._FocusAttnBlockCN)
             return mgfn_ops.focus_attention_block_cn(x, bn, self.to_v, self.rel_pos, self.to_out, self.heads)
-        v = _pointwise(self.to_v, self._batch_norm(x))
+        if mgfn_ops.bn_eval_fold_ok(x, bn, self.to_v):  # eval-mode BN is an affine map: folded into to_v's operand, no launch of its own
+            v = mgfn_ops.to_v_folded_bn(x, bn, self.to_v)
+        else:
+            v = _pointwise(self.to_v, self._batch_norm(x))
         inner = v.shape[0]
         h = self.heads
         v = v.view(inner // h, h, b, n)  # channel = c_idx*heads + h_idx  ("b (c h) n -> (b c) h n")
@@ -288,6 +297,7 @@ class FocusAttention(nn.Module):
         if mgfn_ops.fused_ok(x) and k in (3, 5):  # the per-head depth-wise temporal conv as one HIP launch (fwd) / one (bwd)
             out = mgfn_ops.dwconv_t(v.reshape(inner, b, n), self.rel_pos.weight, self.rel_pos.bias)
             return _pointwise(self.to_out, out, residual)
+        mgfn_ops.torch_path(x, f"depth-wise temporal conv with k = {k} (the kernel is built for 3 and 5)")
         vp = F.pad(v, (k // 2, k // 2))
         w = self.rel_pos.weight[:, 0]  # (h, k): one temporal filter per head
         out = self.rel_pos.bias.view(1, h, 1, 1)
@@ -465,6 +475,7 @@ class MGFNForVideoAnomalyDetection(MGFNPreTrainedModel):
         if mgfn_ops.head_ok(y, self.layer_norm, self.fc):  # LayerNorm + Linear + sigmoid on the body's layout: one HIP launch
             x, scores = mgfn_ops.head_ln_fc(y, self.layer_norm, self.fc)
         else:
+            mgfn_ops.torch_path(y, "head (LayerNorm + Linear + sigmoid) off the fused kernel")
             x = self.layer_norm(body.permute(0, 2, 1))   # (bs*ncrops, T, last_dim)
             scores = self.sigmoid(self.fc(x))
         abn_s, nor_s, a_feat, n_feat, sc = self.magnitude_selection_and_score_prediction(x, scores, bs, ncrops)

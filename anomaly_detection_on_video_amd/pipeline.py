@@ -10,8 +10,7 @@ clip-level anomaly scores.
 from __future__ import annotations
 
 import os
-from math import gcd
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import torch
 
@@ -32,19 +31,34 @@ class FrameCrops:
 
 
 class ExtractScoreStream:
-    def __init__(self, backbone, scorer, clips_per_video: int = 32, ncrops: int = 10, local_batch: int = 32,
+    """`clips_per_video`: one clip count for every video, or a sequence -- video v has `clips_per_video[v % len]` clips of `ncrops`
+    crop-clips each: the variable-length stream extract_features.py produces (one (n_clips, 10, 2048) array per video,
+    /root/reference/extract_features.py:93-100, 104-110; UCF-Crime: 50..500 clips).  A global batch may end one video and begin the
+    next; every video is scored with T = its own clip count (runner.py:42-50)."""
+
+    def __init__(self, backbone, scorer, clips_per_video: Union[int, Sequence[int]] = 32, ncrops: int = 10, local_batch: int = 32,
                  world: int = 1, rank: int = 0, feat_dim: int = 2048):
         self.backbone, self.scorer = backbone, scorer
-        self.clips_per_video, self.ncrops = clips_per_video, ncrops
+        self._clips = [int(clips_per_video)] if isinstance(clips_per_video, int) else [int(c) for c in clips_per_video]
+        if not self._clips or min(self._clips) < 1:
+            raise ValueError("clips_per_video: a positive clip count, or a non-empty sequence of them")
+        self.clips_per_video = self._clips[0] if len(self._clips) == 1 else tuple(self._clips)
+        self.ncrops = ncrops
         self.local_batch, self.world, self.rank = local_batch, world, rank
-        self.per_video = clips_per_video * ncrops
         self.global_batch = local_batch * world
-        lcm = self.per_video * self.global_batch // gcd(self.per_video, self.global_batch)
-        self.ring_rows = lcm
+        # The ring holds the last `ring_rows` feature rows of the stream, ring_rows >= longest video + one global batch and a multiple of
+        # the global batch (a batch never wraps).  Rows [0, max_video_rows) are mirrored behind the ring's end, so that every video
+        # -- also one whose rows wrap around -- is ONE contiguous (n_clips * ncrops, C) window: no gather, no concatenation.
+        self.max_video_rows = max(self._clips) * ncrops
+        gb = self.global_batch
+        self.ring_rows = -(-(self.max_video_rows + gb) // gb) * gb
         dev = next(backbone.parameters()).device
-        self.ring = torch.zeros((self.ring_rows, feat_dim), device=dev, dtype=torch.float32)
+        self.ring = torch.zeros((self.ring_rows + self.max_video_rows, feat_dim), device=dev, dtype=torch.float32)
+        self._vid = 0        # the oldest video whose last crop-clip has not arrived yet ...
+        self._vid_start = 0  # ... and the stream position of its first row
         self.pos = 0  # global stream position (crop-clips consumed so far)
         self.videos_scored = 0
+        self.scored_log: List[Tuple[int, int]] = []  # (video, its clip count) of every video this rank scored
         self.last_scores: Optional[torch.Tensor] = None
         # eval scoring of one video is ~200 tiny launches; ADV_SCORE_GRAPH=1 replays it as one hipGraph
         # (opt-in: measured neutral on throughput, the launches already overlap the backbone)
@@ -177,29 +191,61 @@ class ExtractScoreStream:
             if ev is not None:
                 cur.wait_event(ev)
 
+    def video_rows(self, v: int) -> int:
+        return self._clips[v % len(self._clips)] * self.ncrops
+
+    def seek(self, pos: int) -> None:
+        """Continue a stream at crop-clip `pos` (a multiple of the global batch): the videos that end before `pos` count as done,
+        the one `pos` falls into is scored when its last crop-clip arrives -- from the rows ingested from here on (its earlier rows
+        are whatever the ring holds: zeros on a fresh stream)."""
+        if pos % self.global_batch or pos < 0:
+            raise ValueError(f"seek: {pos} is not a multiple of the global batch {self.global_batch}")
+        v, start = 0, 0
+        while start + self.video_rows(v) <= pos:
+            start += self.video_rows(v)
+            v += 1
+        self.pos, self._vid, self._vid_start = pos, v, start
+
+    def _completing(self) -> List[Tuple[int, int, int]]:
+        """(video, stream position of its first row, rows) of every video whose last crop-clip arrives with the NEXT global batch."""
+        out, v, start = [], self._vid, self._vid_start
+        while start + self.video_rows(v) <= self.pos + self.global_batch:
+            out.append((v, start, self.video_rows(v)))
+            start += self.video_rows(v)
+            v += 1
+        return out
+
     def _videos_completing(self) -> List[int]:
         """Videos of this rank whose last crop-clip arrives with the NEXT global batch."""
-        first_done = self.pos // self.per_video
-        return [v for v in range(first_done, (self.pos + self.global_batch) // self.per_video) if v % self.world == self.rank]
+        return [v for v, _s, _n in self._completing() if v % self.world == self.rank]
 
     @torch.no_grad()
     def ingest(self, gathered: torch.Tensor) -> List[Tuple[int, torch.Tensor]]:
         """Append one global batch of feature rows (stream order) to the ring and score every video
         owned by this rank (video v -> rank v % world) whose last crop-clip just arrived."""
-        if gathered.shape[0] != self.global_batch:
-            raise ValueError(f"expected {self.global_batch} rows per global batch, got {gathered.shape[0]}")
+        gb = self.global_batch
+        if gathered.shape[0] != gb:
+            raise ValueError(f"expected {gb} rows per global batch, got {gathered.shape[0]}")
         start = self.pos % self.ring_rows
-        self.ring[start : start + self.global_batch].copy_(gathered)
-        mine = self._videos_completing()
-        self.pos += self.global_batch
+        self.ring[start : start + gb].copy_(gathered)
+        if start < self.max_video_rows:  # the mirror of the ring's head
+            m = min(gb, self.max_video_rows - start)
+            self.ring[self.ring_rows + start : self.ring_rows + start + m].copy_(gathered[:m])
+        done = self._completing()
+        self.pos += gb
+        if done:
+            v, s, n = done[-1]
+            self._vid, self._vid_start = v + 1, s + n
+        mine = [(v, s, n) for v, s, n in done if v % self.world == self.rank]
         scored = []
         hook, self._after_ring_read = self._after_ring_read, None
-        for v in mine:
-            r0 = (v * self.per_video) % self.ring_rows
-            vid = self.ring[r0 : r0 + self.per_video].view(self.clips_per_video, self.ncrops, -1)
-            if v == mine[-1]:
+        for v, s, n in mine:
+            r0 = s % self.ring_rows
+            vid = self.ring[r0 : r0 + n].view(n // self.ncrops, self.ncrops, -1)
+            if v == mine[-1][0]:
                 self._after_ring_read = hook  # the ring is free for the next step once the last video has been read
             scored.append((v, self.score_video(vid)))
+            self.scored_log.append((v, n // self.ncrops))
         return scored
 
     @torch.no_grad()

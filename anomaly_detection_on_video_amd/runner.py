@@ -70,7 +70,8 @@ class VideoAnomalyDetectionRunner:
         # instead of ~25 multi-tensor ones: 0.73 -> 0.3 ms of the 19-ms step)
         # and with its step counters on the device (capturable): the whole step can then be replayed as one HIP graph
         fused = bool(params) and all(p.is_cuda for p in params)
-        if fused and os.environ.get("ADV_HIP_ADAM", "1") == "1":
+        hip_ok = fused and all(p.dtype == torch.float32 and p.is_contiguous() for p in params)  # (bf16 / channels_last parameters: torch's Adam)
+        if hip_ok and os.environ.get("ADV_HIP_ADAM", "1") == "1":
             # ... and here the whole update as one launch per 80 tensors (optim.HipAdam: torch.optim.Adam's rule and state layout)
             from .optim import HipAdam
 

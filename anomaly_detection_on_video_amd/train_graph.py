@@ -1,8 +1,8 @@
 """One MGFN training step -- zero_grad -> forward -> four losses -> backward -> Adam -- replayed as ONE HIP graph.
 
-The eager step issues ~600 launches from Python autograd (the hand-written GEMM / LayerNorm / MIL / loss kernels through
-ctypes, plus the torch ops of stage 0 and the attention einsums): on a slow host the step is bound by that issue loop, not
-by the GPU (22.0 ms driver-timed against 17.5-18.7 ms on a faster host, same kernels).  The runner feeds a fixed
+The eager step issues ~215 launches from Python autograd (the hand-written GEMM / norm / attention / MIL / loss / Adam kernels
+through ctypes; round 2: ~600, stage 0 and the attention einsums still on torch ops then): on a slow host the step is bound by
+that issue loop, not by the GPU (round 2: 22.0 ms driver-timed against 17.5-18.7 ms on a faster host, same kernels).  The runner feeds a fixed
 `(2B, 10, 32, 2049)` shape (/root/reference/src/runner.py:29-39, configs/data: batch_size 16), so after a few eager steps
 the step is captured once (torch.cuda.CUDAGraph: every launch of this package goes to torch's current stream, nothing
 inside allocates or synchronises outside torch's allocator) and replayed with the batch copied into static buffers:
@@ -40,7 +40,9 @@ class GraphedTrainStep:
             if not g.get("capturable", False):
                 raise ValueError("GraphedTrainStep needs an optimizer created with capturable=True (device-side step counters)")
         self.model, self.optimizer = model, optimizer
-        self.eager_left = eager_steps
+        # at least one eager step before any capture: it builds what a capture must not (pack plans, gather tables, constants and
+        # HipAdam's flat step-counter tensor are created with blocking host -> device copies)
+        self.eager_left = max(int(eager_steps), 1)
         self.clip, self.overlap = clip_grad_norm, overlap
         self.after_step = after_step
         self.graph: Optional[torch.cuda.CUDAGraph] = None
@@ -74,7 +76,10 @@ class GraphedTrainStep:
         groups = tuple((float(g["lr"]) if not torch.is_tensor(g["lr"]) else ("t", g["lr"].data_ptr()), tuple(g.get("betas", ())), g.get("eps"),
                         g.get("weight_decay"), g.get("amsgrad"), g.get("maximize"), tuple(p.data_ptr() for p in g["params"]))
                        for g in self.optimizer.param_groups)
-        return (groups, self.clip, tuple(p.data_ptr() for p in self.model.parameters()))
+        state = self.optimizer.state  # (optimizer.load_state_dict() replaces these tensors: a replay would update orphaned moments)
+        moments = tuple(tuple(state[p][k].data_ptr() if torch.is_tensor(state[p].get(k)) else None for k in ("exp_avg", "exp_avg_sq", "step"))
+                        for g in self.optimizer.param_groups for p in g["params"] if p in state)
+        return (groups, self.clip, tuple(p.data_ptr() for p in self.model.parameters()), moments)
 
     def _finish(self) -> None:
         mgfn_ops.invalidate_caches()  # (fused / captured optimizers do not move version counters)
@@ -86,9 +91,10 @@ class GraphedTrainStep:
         if self.graph is not None and key == self._key and self._baked() != self._stamp:
             # a parameter moved or an optimizer scalar changed since the capture: the graph is stale -> capture again below
             # (or, after MAX_CAPTURES of them, keep to the eager step, which reads everything live)
+            # ONE live eager step first: a moved parameter means new pack plans / tables, a replaced optimizer state new step-counter
+            # bindings -- all built with host -> device copies that are illegal inside a capture
             self.graph, self.static, self.loss, self.held_plans = None, None, None, []
-            if self.captures >= self.MAX_CAPTURES:
-                self.eager_left = 1 << 62
+            self.eager_left = 1 << 62 if self.captures >= self.MAX_CAPTURES else 1
         if self.graph is not None and key == self._key:
             for dst, src in zip(self.static, (video, abnormal_labels, normal_labels)):
                 dst.copy_(src)

@@ -70,6 +70,28 @@ def kernels_sha16() -> str:
     return h.hexdigest()[:16]
 
 
+def ucf_crime_clip_counts(n: int = 64, seed: int = 2024):
+    """Clip counts of a UCF-Crime-shaped stream (SURVEY.md 8(d) cfg 3): n_clips ~ U[50, 500] per video, seeded; the stream walks
+    the list cyclically.  Every video is `n_clips x 10 crops` crop-clips (/root/reference/extract_features.py:93-100)."""
+    import random
+
+    rng = random.Random(seed)
+    return [rng.randint(50, 500) for _ in range(n)]
+
+
+def stream_start(clips, ncrops: int, global_batch: int, warmup: int, steps: int) -> int:
+    """Where the synthetic stream is picked up (a multiple of the global batch): such that a video's last crop-clip arrives in the
+    middle of the K timed steps whatever N, K and W are -- the timed region always holds at least one whole-video MIL scoring
+    pass (T = that video's clip count), i.e. never less than the stream's amortised scoring share (one per ~86 steps at N = 1)."""
+    mid = (warmup + max(steps // 2, 1)) * global_batch
+    end, v = 0, 0
+    while True:
+        end += clips[v % len(clips)] * ncrops
+        if end >= mid:
+            return (end - mid) // global_batch * global_batch
+        v += 1
+
+
 def launch_ranks(n: int, argv) -> int:
     """`python bench.py --gpus N` outside torchrun: start the N rank processes (one per GPU) through
     torch.distributed.run and relay rank 0's JSON line.  Called BEFORE this process has touched the GPU (a process
@@ -153,6 +175,76 @@ def cpu_baseline(budget_s: float = 12.0):
     }
 
 
+def dry_run(args, clips, rank: int, world: int):
+    """`--dry-run`: the N-rank control flow of the real run on CPU tensors -- the same ExtractScoreStream (ring, variable-length
+    video bookkeeping, owner rule), the same all-gather per step (gloo), the same barrier / max-over-ranks timing and result line --
+    with a stand-in backbone (rows = the crop-clips' stream positions) and a stand-in scorer.  Rank 0 returns the line (others {})
+    after checking that every gathered row arrived in stream order and every completed video was scored once, by its owner."""
+    from anomaly_detection_on_video_amd import dist as adist
+    from anomaly_detection_on_video_amd.pipeline import ExtractScoreStream
+
+    class Rows(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, x):
+            return x.expand(-1, 8)
+
+    class Stream(ExtractScoreStream):
+        def score_video(self, feats):
+            self.videos_scored += 1
+            return feats[:, 0, 0].clone()
+
+    st = Stream(Rows(), None, clips_per_video=clips, ncrops=10, local_batch=args.batch, world=world, rank=rank, feat_dim=8)
+    gb = args.batch * world
+    pos0 = stream_start(clips, 10, gb, args.warmup, args.steps)
+    st.seek(pos0)
+    scored = []
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    def run(k0, n):
+        for k in range(k0, k0 + n):
+            pos = pos0 + k * gb + rank * args.batch
+            g, sc = st.step(torch.arange(pos, pos + args.batch, dtype=torch.float32).unsqueeze(1))
+            assert torch.equal(g[:, 0], torch.arange(pos0 + k * gb, pos0 + (k + 1) * gb, dtype=torch.float32)), "gathered rows out of stream order"
+            scored.extend(v for v, _s in sc)
+
+    run(0, args.warmup)
+    barrier()
+    before = len(scored)
+    t0 = time.perf_counter()
+    run(args.warmup, args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.zeros(world, dtype=torch.float64)
+    t[rank] = elapsed
+    n_scored = torch.tensor([float(len(scored))])
+    if world > 1:
+        torch.distributed.all_reduce(t)
+        torch.distributed.all_reduce(n_scored)
+    assert all(v % world == rank for v in scored) and len(set(scored)) == len(scored)
+    end = pos0 + (args.warmup + args.steps) * gb  # every video that ends inside the stream fed so far was scored by exactly one rank
+    s0, v, done = 0, 0, 0
+    while s0 + clips[v % len(clips)] * 10 <= end:
+        s0 += clips[v % len(clips)] * 10
+        done += s0 > pos0  # (seek: a video that ends at or before the start counts as done)
+        v += 1
+    assert int(n_scored.item()) == done, (int(n_scored.item()), done)
+    if rank != 0:
+        return {}
+    slowest = float(t.max())
+    return {"metric": metric_name(), "dry_run": True, "value": round(gb * args.steps / slowest, 2), "unit": "clips/s (CPU stand-in backbone: NOT a measurement)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
+            "config": {"local_batch": args.batch, "global_batch": gb, "clips_per_video": "U[50,500] seeded", "stream_start": pos0,
+                       "videos_scored_all_ranks": int(n_scored.item()), "videos_scored_rank0_timed": len(scored) - before,
+                       "backend": torch.distributed.get_backend() if world > 1 else "none (single process)",
+                       "world_size_observed": torch.distributed.get_world_size() if world > 1 else 1}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,14 +277,14 @@ def main():
     if aops.ARITH != "f32":  # the line below prices the step against the fp32 MFMA peak and says dtype f32: refuse anything else
         raise SystemExit(f"bench.py: ADV_ARITH={aops.ARITH!r} switches conv kernels to split-bf16 arithmetic; the reported line is "
                          "the exact-fp32 path (dtype f32, 157.3 TFLOP/s roofline) -- unset ADV_ARITH")
-    if args.dry_run:  # no GPU call anywhere on this path
+    clips = ucf_crime_clip_counts()
+    if args.dry_run:  # no GPU call anywhere on this path: the rank launch, the rendezvous, the stream's bookkeeping, the result line
         adist.init_process_group("gloo")
-        n = torch.ones(1)
-        if world > 1:
-            torch.distributed.all_reduce(n)
-            torch.distributed.destroy_process_group()
+        line = dry_run(args, clips, rank, world)
         if rank == 0:
-            print(json.dumps({"metric": metric_name(), "dry_run": True, "n_gpus": int(n.item()), "steps": args.steps, "warmup": args.warmup}), flush=True)
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
@@ -211,7 +303,12 @@ def main():
     scorer = MGFNForVideoAnomalyDetection(MGFNConfig())
     scorer.load_state_dict(synth_module_state_dict(scorer))
     scorer = scorer.eval().to(dev)
-    stream = ExtractScoreStream(backbone, scorer, clips_per_video=32, ncrops=10, local_batch=args.batch, world=world, rank=rank)
+    # the synthetic UCF-Crime-shaped stream (SURVEY 8(d) cfg 3): n_clips ~ U[50, 500] per video, 10 crops per clip; every video is
+    # scored with T = its own clip count when its last crop-clip has arrived
+    stream = ExtractScoreStream(backbone, scorer, clips_per_video=clips, ncrops=10, local_batch=args.batch, world=world, rank=rank)
+    pos0 = stream_start(clips, 10, args.batch * world, args.warmup, args.steps)
+    stream.seek(pos0)
+    stream.ring.uniform_(0.0, 3.0)  # (the rows of the picked-up video that lie before the stream's start: plausible features, not zeros)
 
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.randn((args.batch, 3, 16, 224, 224), device=dev, generator=gen)
@@ -236,6 +333,7 @@ def main():
     orig_forward = backbone.forward
     backbone.forward = lambda b: backbone.forward_single(b, events=events)
     videos_before = stream.videos_scored
+    log_before = len(stream.scored_log)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         stream.step_async(x)
@@ -243,6 +341,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     videos_timed = stream.videos_scored - videos_before  # (the counter keeps running through the sustained / PCIe legs below)
+    clips_timed = [n for _v, n in stream.scored_log[log_before:]]
     backbone.forward = orig_forward
     rank_elapsed = [elapsed]
     backend_observed, world_observed = "none (single process)", 1
@@ -457,11 +556,12 @@ def main():
             "dtype": "f32",
             "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share one GPU, gloo)",
             "config": {
-                "workload": "I3D-RGB feature extraction, batch=32 clips, 1xMI355X (HIP conv3d + fused BN/ReLU) -> MGFN MIL score per 32-clip x 10-crop video"
+                "workload": "I3D-RGB feature extraction, batch=32 clips, 1xMI355X (HIP conv3d + fused BN/ReLU) -> MGFN MIL score per video (T = its clip count) x 10 crops"
                 if world == 1 else
                 f"I3D-RGB extraction sharded over {world}xMI355X, RCCL all-gather of 2048-d features, synthetic UCF-Crime-shape stream -> MGFN MIL score",
                 "clip": "3x16x224x224 fp32", "local_batch": args.batch, "global_batch": args.batch * world,
-                "clips_per_video": 32, "ncrops": 10, "videos_scored_rank0": videos_timed,
+                "clips_per_video": "n_clips ~ U[50,500] per video, seeded (SURVEY 8(d) cfg 3); stream picked up at crop-clip %d" % pos0,
+                "ncrops": 10, "videos_scored_rank0": videos_timed, "clips_of_videos_scored_rank0": clips_timed,
                 "weights": "deterministic synthetic (no network)", "parallelism": f"dp{world}",
                 "backend": backend_observed, "world_size_observed": world_observed,  # what torch.distributed reports, not what was asked for
                 "rank_clips_per_s_min": round(args.batch * args.steps / max(rank_elapsed), 2),
@@ -471,6 +571,8 @@ def main():
             "roofline": {
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                # HBM-side GB/s of the conv stack: the profiled bytes per launch set over THIS run's measured time per launch set
+                "hbm_gbps": None if traffic is None else round(traffic / (conv_ms_avg * 1e-3) / 1e9, 1), "hbm_peak_gbps": 8000.0,
                 "traffic_unit": "bytes per launch set (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes in profiles/)",
                 "traffic_source": traffic_src,
                 "kernel": "conv3d fp32-MFMA stack (53 launches per step on rank 0)" if not overlapped else

@@ -486,6 +486,24 @@ int advhip_glance_attention_fwd_f32(const float* qkv, float* out, float* p, int3
 int advhip_glance_attention_bwd_f32(const float* dout, const float* qkv, const float* p, float* dqkv, int32_t heads, int64_t B,
                                     int32_t T, int32_t dim_head, float scale, void* stream);
 
+/* The same core for ANY T (dim_head = 64) -- the validation pass scores a whole video, T = n_clips
+ * (/root/reference/src/runner.py:42-50 -> modeling_mgfn.py:107-123): one workgroup per (32-query tile, sequence, head), key / value
+ * tiles of 32 clips through LDS with an online softmax; the T x T attention matrix never exists in memory.  lse (B, heads, T) =
+ * log-sum-exp of every row of scale * q^T k (nullable: inference) replaces p for the backward pass, which recomputes the softmax
+ * tile by tile from qkv, out and lse (dq per query tile, dk / dv per key tile: every output written once, sums in tile order). */
+int advhip_glance_attention_fwd_anyt_f32(const float* qkv, float* out, float* lse, int32_t heads, int64_t B, int32_t T, int32_t dim_head,
+                                         float scale, void* stream);
+int advhip_glance_attention_bwd_anyt_f32(const float* dout, const float* qkv, const float* out, const float* lse, float* dqkv, int32_t heads,
+                                         int64_t B, int32_t T, int32_t dim_head, float scale, void* stream);
+
+/* A per-input-channel affine map x -> mul[c] x[c] + add[c] folded into the 1x1 layer W (O, C) (+ bias, nullable) that follows it:
+ *   Wf[o][c] = W[o][c] mul[c];  bias_f[o] = bias[o] + sum_c W[o][c] add[c] (add nullable: 0);  rowsum[o] = sum_c Wf[o][c] (nullable).
+ * Eval-mode nn.BatchNorm1d in front of FocusAttention.to_v (modeling_mgfn.py:162, 173-174; mul / add = advhip_bn_fold_f32's scale / shift)
+ * and MGFNLayerNorm's (g, b) in front of MGFNFeedForward.in_conv at inference (modeling_mgfn.py:36-64): operand-build time, once per
+ * set of weights -- the scoring pass itself then has no normalisation launch and no torch arithmetic for these layers. */
+int advhip_fold_affine_f32(const float* W, const float* mul, const float* add, const float* bias, float* Wf, float* bias_f, float* rowsum,
+                           int32_t O, int32_t C, void* stream);
+
 /* The scorer's head on the body's (C, N) layout (modeling_mgfn.py:387-389: permute -> nn.LayerNorm(C) -> nn.Linear(C, 1) -> sigmoid):
  * xn (N, C) = LayerNorm over C of y (C, N) -- transposed through LDS, so that the MIL head reads rows --, score[n] =
  * sigmoid(xn[n, :] . fc_w + fc_b[0]); mean / rstd (N) kept for the backward pass.  Backward: dy (C, N) from d_xn (N, C) and

@@ -285,6 +285,62 @@ def test_stream_ring_orders_videos_like_the_reference():
                 streams[0].ingest(torch.zeros(gb + 1, 8))
 
 
+def test_stream_ring_variable_length_videos():
+    """A UCF-Crime-shaped stream (SURVEY 8(d) cfg 3): every video has its own clip count, a global batch may end one video and
+    begin the next (or hold several whole ones), the ring wraps many times.  Every video must come out exactly once, on rank
+    v % world, as ONE contiguous window of rows [start_v, start_v + n_v * crops) viewed (n_v clips, crops) --
+    /root/reference/extract_features.py:93-100 builds exactly that array per video."""
+    import random
+
+    from anomaly_detection_on_video_amd.pipeline import ExtractScoreStream
+
+    class S(ExtractScoreStream):
+        def score_video(self, feats):
+            self.videos_scored += 1
+            assert feats.is_contiguous()
+            return feats[:, :, 0].clone()
+
+    rng = random.Random(5)
+    for world, local_batch, crops, lo, hi in ((1, 32, 10, 50, 500), (2, 16, 10, 5, 60), (3, 7, 5, 1, 9), (8, 32, 10, 50, 500), (1, 64, 2, 1, 3)):
+        clips = [rng.randint(lo, hi) for _ in range(11)]
+        streams = [S(_FakeBackbone(), None, clips_per_video=clips, ncrops=crops, local_batch=local_batch, world=world, rank=r, feat_dim=4)
+                   for r in range(world)]
+        gb = local_batch * world
+        assert streams[0].ring_rows % gb == 0 and streams[0].ring_rows >= max(clips) * crops + gb
+        total = 3 * sum(clips) * crops + gb  # the clip-count list is walked three times: the ring wraps, the list cycles
+        got, pos = {}, 0
+        while pos < total:
+            rows = torch.arange(pos, pos + gb, dtype=torch.float32).unsqueeze(1).expand(-1, 4).contiguous()
+            for r, st in enumerate(streams):
+                for v, ids in st.ingest(rows):
+                    assert v % world == r and v not in got
+                    got[v] = ids
+            pos += gb
+        starts, v, s0 = {}, 0, 0
+        while s0 + clips[v % 11] * crops <= pos:
+            starts[v] = s0
+            s0 += clips[v % 11] * crops
+            v += 1
+        assert sorted(got) == sorted(starts) and len(got) >= 33
+        for v, ids in got.items():
+            n = clips[v % 11]
+            assert torch.equal(ids, torch.arange(starts[v], starts[v] + n * crops, dtype=torch.float32).view(n, crops))
+    # seek: a stream continued in the middle of video 1 scores video 1 when its last row arrives, then video 2
+    st = S(_FakeBackbone(), None, clips_per_video=[3, 4, 2], ncrops=2, local_batch=2, feat_dim=4)
+    st.seek(8)  # video 0 = rows 0..5, video 1 = rows 6..13
+    seen = []
+    for pos in range(8, 20, 2):
+        rows = torch.arange(pos, pos + 2, dtype=torch.float32).unsqueeze(1).expand(-1, 4).contiguous()
+        seen += st.ingest(rows)
+    assert [v for v, _ in seen] == [1, 2]
+    assert torch.equal(seen[0][1].reshape(-1)[2:], torch.arange(8, 14, dtype=torch.float32))  # rows 6, 7 were never fed: the ring's zeros
+    assert torch.equal(seen[1][1].reshape(-1), torch.arange(14, 18, dtype=torch.float32))
+    with pytest.raises(ValueError):
+        st.seek(3)
+    with pytest.raises(ValueError):
+        S(_FakeBackbone(), None, clips_per_video=[4, 0], ncrops=2, local_batch=2, feat_dim=4)
+
+
 def test_checkpoint_carries_the_keys_lightning_reads():
     """A last.ckpt written here must be loadable by the reference's Lightning trainer: its loader indexes
     `pytorch-lightning_version` unconditionally (migration step), then reads `state_dict` (keys prefixed `model.`, the

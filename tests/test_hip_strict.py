@@ -1,0 +1,174 @@
+"""The scorer never leaves the HIP kernels: every test here runs with `mgfn_ops.STRICT` on (ADV_MGFN_STRICT=1), under which a layer
+that would take the torch expression of its arithmetic raises instead -- at the training shape (T = 32), at whole-video validation
+shapes (T = n_clips, /root/reference/src/runner.py:42-50) and on the variable-length extract -> score stream bench.py times.
+On top of that an ATen audit (a TorchDispatchMode) lists every torch operator a scoring pass dispatches: only allocation, views
+and copies may appear -- no matmul / softmax / norm / element-wise arithmetic."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+
+from conftest import GOLDEN, rel_err
+from anomaly_detection_on_video_amd.weights import synth_i3d_state_dict, synth_module_state_dict, synth_tensor
+from test_oracle_golden import mgfn_inputs
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+DEV = "cuda:0"
+
+# what a HIP-only pass may ask torch for: memory, views, copies -- nothing that computes
+PLUMBING = {
+    "empty", "empty_like", "empty_strided", "new_empty", "new_empty_strided", "zeros", "zeros_like", "ones", "ones_like", "full", "zero_", "fill_",
+    "view", "_unsafe_view", "reshape", "_reshape_alias", "permute", "transpose", "t", "slice", "select", "unsqueeze", "squeeze", "expand", "as_strided",
+    "alias", "detach", "clone", "copy_", "_to_copy", "contiguous", "split", "split_with_sizes", "unbind", "narrow", "unfold", "lift_fresh", "is_same_size",
+    "record_stream", "_local_scalar_dense", "cat", "stack", "resize_",
+    "_record_function_enter_new", "_record_function_exit",  # (profiler range markers torch.optim wraps a step in)
+}
+
+
+class AtenAudit(TorchDispatchMode):
+    def __init__(self):
+        super().__init__()
+        self.ops = {}
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = func.overloadpacket.__name__
+        self.ops[name] = self.ops.get(name, 0) + 1
+        return func(*args, **(kwargs or {}))
+
+    def arithmetic(self):
+        return {k: v for k, v in self.ops.items() if k not in PLUMBING}
+
+
+@pytest.fixture
+def strict(monkeypatch):
+    from anomaly_detection_on_video_amd import mgfn_ops
+
+    monkeypatch.setattr(mgfn_ops, "STRICT", True)
+    return mgfn_ops
+
+
+@pytest.fixture(scope="module")
+def scorer_and_sd():
+    from anomaly_detection_on_video_amd.models.mgfn import MGFNConfig, MGFNForVideoAnomalyDetection
+
+    m = MGFNForVideoAnomalyDetection(MGFNConfig())
+    sd = synth_module_state_dict(m, gain=1.0)
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV), sd
+
+
+def test_strict_raises_where_a_layer_would_leave_the_kernels(strict):
+    """The switch is live: a GlanceAttention with dim_head = 32 (outside the kernels' rules) raises under STRICT."""
+    from anomaly_detection_on_video_amd import _lib
+    from anomaly_detection_on_video_amd.models.mgfn.modeling_mgfn import GlanceAttention
+
+    att = GlanceAttention(dim=64, heads=2, dim_head=32).to(DEV).eval()
+    with torch.no_grad(), pytest.raises(_lib.HipExtensionError, match="ADV_MGFN_STRICT"):
+        att(torch.randn(64, 4, 8, device=DEV))
+
+
+def test_eval_odd_T_reference_golden_under_strict(strict, scorer_and_sd):
+    """mgfn.npz's whole-video eval golden (T = 57, made by the reference) with the torch branch closed."""
+    g = np.load(os.path.join(GOLDEN, "mgfn.npz"))
+    model, sd = scorer_and_sd
+    model.load_state_dict(sd)
+    model.eval()
+    model.force_split = False
+    with torch.no_grad():
+        o = model(video=mgfn_inputs(1, 57, 3).to(DEV))
+    assert rel_err(o.scores.cpu(), g["eval57_scores"]) < TOL
+    assert rel_err(o.abnormal_scores.cpu(), g["eval57_abn_scores"]) < TOL
+
+
+@pytest.mark.parametrize("T", [5, 57, 517, 32, 3])  # (T < k = 3: torch.topk raises in the reference too)
+def test_validation_pass_any_T_vs_oracle_under_strict(strict, scorer_and_sd, T):
+    """runner.validation_step's forward -- (1, 10, T, 2049), eval, no split -- for short, odd and long videos against the CPU
+    oracle, every layer on the HIP kernels, and nothing but plumbing dispatched to ATen."""
+    from oracle import mgfn_oracle
+
+    model, sd = scorer_and_sd
+    model.load_state_dict(sd)
+    model.eval()
+    model.force_split = False
+    video = mgfn_inputs(1, T, 11 + T)
+    with torch.no_grad():
+        model(video=video.to(DEV))  # (lazily built operands: tables, packed / folded weights)
+        with AtenAudit() as audit:
+            o = model(video=video.to(DEV))
+        ref = mgfn_oracle.mgfn_forward(video, sd)
+    assert o.scores.shape == (1, T, 1)
+    assert rel_err(o.scores.cpu(), ref.scores) < TOL
+    assert rel_err(o.abnormal_scores.cpu(), ref.abnormal_scores) < TOL
+    assert audit.arithmetic() == {}, f"torch arithmetic on the scoring path: {audit.arithmetic()}"
+
+
+def test_training_step_under_strict_and_its_aten_ops(strict, scorer_and_sd):
+    """One training step at the runner's batch layout (2B = 4 videos x 10 crops x 32 segments) with the torch branch closed:
+    forward, four losses, backward, HipAdam.  The ATen operators it dispatches are listed: what autograd itself adds when a tensor
+    feeds two consumers (`add`, 4 per step), the dropout masks of the MIL head (`native_dropout`, 2), the BatchNorm layers'
+    `num_batches_tracked += 1` (one `_foreach_add_`) and HipAdam's step counters (one `add_`) are the only arithmetic."""
+    from anomaly_detection_on_video_amd.optim import HipAdam
+
+    model, sd = scorer_and_sd
+    model.load_state_dict(sd)
+    model.train()
+    model.injected_keep = None
+    opt = HipAdam(model.parameters(), lr=1e-3, weight_decay=5e-4)
+    video = mgfn_inputs(4, 32, 0).to(DEV)
+    al, nl = torch.ones(2, device=DEV), torch.zeros(2, device=DEV)
+    before = model.fc.weight.detach().clone()
+    with AtenAudit() as audit:
+        opt.zero_grad(set_to_none=True)
+        loss = model(video=video, abnormal_labels=al, normal_labels=nl).loss
+        loss.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and not torch.equal(model.fc.weight.detach(), before)
+    allowed = {"add", "add_", "native_dropout", "_foreach_add_"}
+    extra = {k: v for k, v in audit.arithmetic().items() if k not in allowed}
+    assert extra == {}, f"torch arithmetic in the training step: {extra} (all: {audit.arithmetic()})"
+    assert sum(audit.arithmetic().values()) <= 10, audit.arithmetic()
+    for forbidden in ("mm", "bmm", "matmul", "addmm", "_softmax", "native_layer_norm", "native_batch_norm", "convolution", "gelu", "sigmoid", "rsqrt"):
+        assert forbidden not in audit.ops
+    model.eval()
+    model.zero_grad(set_to_none=True)
+    model.load_state_dict(sd)
+
+
+def test_variable_length_stream_vs_oracle_under_strict(strict):
+    """The stream bench.py times, in miniature: videos of different lengths (5, 3, 9, 4 clips x 2 crops) cut into global batches of
+    4 crop-clips on three HIP stream lanes; every video's scores (T = its clip count) against the CPU oracle's I3D features ->
+    add_magnitude -> MGFN eval, all under STRICT."""
+    from anomaly_detection_on_video_amd.i3d import I3Res50
+    from anomaly_detection_on_video_amd.models.mgfn import MGFNConfig, MGFNForVideoAnomalyDetection
+    from anomaly_detection_on_video_amd.pipeline import ExtractScoreStream
+    from oracle import host_oracle, i3d_oracle, mgfn_oracle
+
+    sd = synth_i3d_state_dict()
+    bb = I3Res50()
+    bb.load_state_dict(sd)
+    bb = bb.eval().to(DEV)
+    sc = MGFNForVideoAnomalyDetection(MGFNConfig())
+    msd = synth_module_state_dict(sc)
+    sc.load_state_dict(msd)
+    sc = sc.eval().to(DEV)
+    clips, crops = [5, 3, 9, 4], 2
+    total = sum(clips) * crops  # 42 crop-clips -> 11 batches of 4 (the last two rows belong to video 4 = clips[0] again, never completed)
+    x = synth_tensor("vstream.x", (44, 3, 16, 48, 48), scale=2.0)
+    stream = ExtractScoreStream(bb, sc, clips_per_video=clips, ncrops=crops, local_batch=4)
+    handles = [stream.step_async(x[i : i + 4].to(DEV)) for i in range(0, 44, 4)]
+    stream.drain()
+    torch.cuda.synchronize()
+    scored = [vs for h in handles for vs in h.result()[1]]
+    assert [v for v, _ in scored] == [0, 1, 2, 3] and stream.scored_log == [(0, 5), (1, 3), (2, 9), (3, 4)]
+    feats = i3d_oracle.i3d_forward(x[:total], sd).reshape(total, 2048)
+    s0 = 0
+    for (v, s), n in zip(scored, clips):
+        f = feats[s0 : s0 + n * crops].reshape(n, crops, 2048).numpy()
+        video = torch.from_numpy(host_oracle.add_magnitude(f)).unsqueeze(0).permute(0, 2, 1, 3)
+        ref = mgfn_oracle.mgfn_forward(video, msd).scores.reshape(-1)
+        assert s.shape == (n,) and rel_err(s.cpu(), ref) < TOL
+        s0 += n * crops

@@ -395,6 +395,95 @@ def test_graphed_training_steps_equal_eager_steps_bit_for_bit(optimizer):
     assert torch.isfinite(graphed(batches[0], al, nl)) and graphed.replays == 4
 
 
+def test_graphed_step_recaptures_after_lr_change_parameter_move_and_state_reload():
+    """What a captured graph bakes in besides shapes (train_graph.GraphedTrainStep._baked): optimizer scalars (lr is a kernel
+    argument of the Adam launch), parameter addresses (`p.data = p.data.clone()` moves the storage: new pack plans, whose item
+    tables are built with a host -> device copy -- illegal inside a capture, so ONE eager step runs first) and the optimizer's
+    moment / step tensors (`load_state_dict` replaces them).  After each such change the graphed loop must (i) notice, (ii) run one
+    live eager step, (iii) capture again, and stay IDENTICAL to the plain eager loop going through the same changes."""
+    import copy
+
+    from anomaly_detection_on_video_amd.models.mgfn import MGFNConfig, MGFNForVideoAnomalyDetection
+    from anomaly_detection_on_video_amd.optim import HipAdam
+    from anomaly_detection_on_video_amd.train_graph import GraphedTrainStep
+
+    def make():
+        m = MGFNForVideoAnomalyDetection(MGFNConfig())
+        m.load_state_dict(synth_module_state_dict(m))
+        m = m.to(DEV).train()
+        ones = torch.ones(2, 32, device=DEV)
+        m.injected_keep = (ones, ones)
+        return m, HipAdam(m.parameters(), lr=1e-3, weight_decay=5e-4)
+
+    nl, al = torch.zeros(2, device=DEV), torch.ones(2, device=DEV)
+    batches = [mgfn_inputs(4, 32, 60 + i).to(DEV) for i in range(14)]
+
+    def run(eager_steps):
+        m, opt = make()
+        step = GraphedTrainStep(m, opt, eager_steps=eager_steps)
+        losses, marks = [], []
+        for i, b in enumerate(batches):
+            if i == 4:
+                for g in opt.param_groups:
+                    g["lr"] = 5e-4
+            if i == 7:
+                w = m.backbone.layers[2][0].ffn.in_conv.weight
+                w.data = w.data.clone()  # same values, new storage
+            if i == 10:
+                opt.load_state_dict(copy.deepcopy(opt.state_dict()))  # every moment / step tensor replaced by a copy
+            losses.append(float(step(b, al, nl)))
+            marks.append((step.captures, step.replays, step.graph is not None, len(step.held_plans)))
+        return m, opt, step, losses, marks
+
+    m_e, opt_e, _s, losses_e, _ = run(1 << 30)
+    m_g, opt_g, step, losses_g, marks = run(2)
+    assert losses_g == losses_e, (losses_g, losses_e)
+    for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
+        assert torch.equal(a, b), k
+    for pe, pg in zip(m_e.parameters(), m_g.parameters()):
+        se, sg = opt_e.state[pe], opt_g.state[pg]
+        assert torch.equal(se["exp_avg"], sg["exp_avg"]) and torch.equal(se["exp_avg_sq"], sg["exp_avg_sq"]) and float(se["step"]) == float(sg["step"]) == 14.0
+    # steps 0-1 eager, 2 captures (#1) and replays, 3 replays; 4: stale (lr) -> eager, 5 captures (#2), 6 replays; 7: stale (moved
+    # parameter) -> eager, 8 captures (#3), 9 replays; 10: stale (optimizer state) -> eager, 11 captures (#4), 12-13 replay
+    assert [c for c, _r, _g, _h in marks] == [0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4], marks
+    assert [g for _c, _r, g, _h in marks] == [False, False, True, True, False, True, True, False, True, True, False, True, True, True], marks
+    assert step.replays == 9 and all(h >= 1 for _c, _r, g, h in marks if g) and all(h == 0 for _c, _r, g, h in marks if not g)
+    # a fifth change: MAX_CAPTURES reached -> the step stays eager from here on (and still tracks the eager loop: same code path)
+    for g in opt_g.param_groups:
+        g["lr"] = 2.5e-4
+    step(batches[0], al, nl)
+    step(batches[1], al, nl)
+    assert step.graph is None and step.captures == GraphedTrainStep.MAX_CAPTURES
+
+
+def test_hip_adam_creates_state_only_for_parameters_with_gradients():
+    """torch.optim.Adam initialises `state[p]` the first time p has a gradient; a frozen parameter never gets an entry, so the
+    state_dict of a partly frozen model has the same keys under both optimizers (a checkpoint interchange requirement)."""
+    from anomaly_detection_on_video_amd.optim import HipAdam
+
+    ps_ref = [torch.randn(5, device=DEV, requires_grad=True) for _ in range(4)]
+    ps_hip = [p.detach().clone().requires_grad_() for p in ps_ref]
+    ref, hip = torch.optim.Adam(ps_ref, lr=1e-3), HipAdam(ps_hip, lr=1e-3)
+    for step in range(3):
+        for i, (a, b) in enumerate(zip(ps_ref, ps_hip)):
+            if i == 2 or (i == 1 and step == 0):  # parameter 2 never has a gradient, parameter 1 gets its first one in step 1
+                a.grad = b.grad = None
+                continue
+            g = torch.full((5,), 0.1 * (i + 1) * (step + 1), device=DEV)
+            a.grad, b.grad = g.clone(), g.clone()
+        ref.step()
+        hip.step()
+    sr, sh = ref.state_dict()["state"], hip.state_dict()["state"]
+    assert sorted(sr) == sorted(sh) == [0, 1, 3]
+    for k in sr:
+        assert float(sr[k]["step"]) == float(sh[k]["step"])
+        assert rel_err(sh[k]["exp_avg"].cpu(), sr[k]["exp_avg"].cpu()) < 2e-6
+    for a, b in zip(ps_ref, ps_hip):
+        assert rel_err(b.detach().cpu(), a.detach().cpu()) < 2e-6
+    with pytest.raises(ValueError):
+        HipAdam(ps_hip, lr=torch.tensor(1e-3))
+
+
 def test_hip_adam_tracks_torch_adam_and_shares_its_state_layout():
     """optim.HipAdam (one launch per 80 tensors) against torch.optim.Adam, the reference's optimizer (/root/reference/src/runner.py:53-59):
     same update after several steps on tensors of ragged sizes (vector body + scalar tails, > 80 tensors = two launches), a
