@@ -64,7 +64,14 @@ def _check(ranks, world, backend, shape="small"):
     cfg = rank_worker.CONFIGS[shape]
     rows, scores = _single_process(world, shape)
     gb = cfg["local_batch"] * world
-    assert len(scores) == cfg["steps"] * gb // (cfg["clips_per_video"] * cfg["ncrops"])  # the videos that complete in the stream
+    cl = cfg["clips_per_video"] if isinstance(cfg["clips_per_video"], list) else [cfg["clips_per_video"]]
+    done, end = 0, 0
+    while end + cl[done % len(cl)] * cfg["ncrops"] <= cfg["steps"] * gb:
+        end += cl[done % len(cl)] * cfg["ncrops"]
+        done += 1
+    assert len(scores) == done and done >= 2  # the videos that complete in the stream
+    for v, s in scores.items():
+        assert s.shape == (cl[v % len(cl)],)  # T = the video's own clip count
     seen = []
     for r, rec in enumerate(ranks):
         assert rec["backend"] == backend and rec["world"] == world
@@ -81,6 +88,22 @@ def test_two_ranks_sharing_the_gpu_over_gloo_equal_one_process(tmp_path):
     ranks = _run_ranks(2, "gloo", True, str(tmp_path))
     assert all(rec["device"] == "cuda:0" for rec in ranks)
     _check(ranks, 2, "gloo")
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_variable_length_stream_ranks_sharing_the_gpu_equal_one_process(tmp_path, world):
+    """BASELINE config 3's stream shape (videos of different lengths) on 2 and on 4 rank processes sharing cuda:0 over gloo: every rank
+    holds every gathered row in stream order, video v (T = its own clip count) is scored once, by rank v % W, with the bits one
+    process gives.  World 4 is the widest rehearsal one card allows (first-contact insurance for the 8-rank run)."""
+    ranks = _run_ranks(world, "gloo", True, str(tmp_path), shape="ragged")
+    _check(ranks, world, "gloo", shape="ragged")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs: one rank per GPU over RCCL")
+def test_variable_length_stream_over_rccl_equals_one_process(tmp_path):
+    world = min(torch.cuda.device_count(), 8)
+    ranks = _run_ranks(world, "nccl", False, str(tmp_path), shape="ragged")
+    _check(ranks, world, "nccl", shape="ragged")
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs: one rank per GPU over RCCL")
