@@ -16,7 +16,10 @@ namespace advhip {
 // groups split C and combine through LDS.  N = 10240 positions give 320 blocks (64-position blocks: 160 for 256 CUs) and
 // the channel loops are unrolled eight-fold -- these kernels live on bytes in flight (round 2: 42 / 68 us fwd / bwd at
 // 1024 x 10240 with 64 positions x 4 waves, ~2 TB/s).
-constexpr int LN_COLS = 32, LN_GROUPS = 16, LN_THREADS = LN_COLS * LN_GROUPS, LN_UNROLL = 8;
+#ifndef ADV_LN_COLS
+#define ADV_LN_COLS 32
+#endif
+constexpr int LN_COLS = ADV_LN_COLS, LN_GROUPS = 512 / LN_COLS, LN_THREADS = LN_COLS * LN_GROUPS, LN_UNROLL = 8;
 
 // per-position mean and 1 / (std_biased + eps) of x[:, n] in one read: sums of d = x - x[0, n] and d^2 (the shift keeps
 // s2 / C - (s1 / C)^2 free of cancellation: d is of the order of the spread, whatever the mean)
@@ -181,6 +184,128 @@ __global__ __launch_bounds__(LN_THREADS) void chan_layernorm_bwd_kernel(const fl
   }
 }
 
+// The same backward for the shapes the scorer has (C = 64 / 128 / 1024, N a multiple of 4), re-blocked around what bounds it.  The
+// kernel above gives every lane ONE position and a 16th of the channels: a dword per lane and access (the texture addresser takes
+// 16 cycles per 256-byte wave-instruction: ~17 us per 512-KB block whatever HBM does), ten cross-lane shuffles per channel and
+// thread for the per-channel sums, and dy / x read twice.  Here a lane owns FOUR consecutive positions (16-byte accesses: a
+// quarter of the wave-instructions) and a 64th of the channels, with every value resident in registers between the statistics
+// and the output (CPT = C / 64 float4 pairs per thread: 128 VGPRs at C = 1 024; a block has its CU to itself at N / 32 = 320
+// blocks on 256 CUs), the per-channel sums fold the lane's four positions first (three shuffle steps over 8 lanes instead of five
+// over 32), the per-position sums fold across the wave's 8 channel groups by shuffles and across the 8 waves through LDS.
+// Same formulas; the sums associate differently from the kernel above (1e-7 relative).  Stage-2 launch (1 024 x 10 240, + skip
+// gradient): profiles/r05_mgfn_passes.md.
+constexpr int LV_POS = 32, LV_PL = 8, LV_GROUPS = 64, LV_THREADS = LV_PL * LV_GROUPS;  // 8 position quads x 64 channel groups
+template <int CPT>
+__global__ __launch_bounds__(LV_THREADS) void chan_layernorm_bwd_v4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                           const float* __restrict__ g, const float* __restrict__ mu,
+                                                                           const float* __restrict__ rs, float* __restrict__ dx,
+                                                                           float* __restrict__ pg, float* __restrict__ pb, long long N,
+                                                                           float eps, const float* __restrict__ add, long long prow) {
+  constexpr int Cc = CPT * LV_GROUPS;
+  __shared__ float part[2][LV_THREADS / 64][LV_POS];
+  const int pl = threadIdx.x % LV_PL, grp = threadIdx.x / LV_PL, wave = threadIdx.x >> 6;
+  const long long n = blockIdx.x * (long long)LV_POS + 4 * pl;  // N % 4 == 0: a quad is inside the tensor or past it
+  const bool ok = n < N;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 mean = zero4, r = zero4, d[CPT], xc[CPT];
+#pragma unroll
+  for (int u = 0; u < CPT; ++u) d[u] = xc[u] = zero4;
+  if (ok) {  // (a branch, not a select between addresses: the loads stay 16-byte global loads)
+    mean = *reinterpret_cast<const float4*>(mu + n);
+    r = *reinterpret_cast<const float4*>(rs + n);
+    const float* dyp = dy + (long long)grp * N + n;
+    const float* xp = x + (long long)grp * N + n;
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+      d[u] = *reinterpret_cast<const float4*>(dyp + (long long)u * LV_GROUPS * N);
+      xc[u] = *reinterpret_cast<const float4*>(xp + (long long)u * LV_GROUPS * N);
+    }
+  }
+  float4 s1 = zero4, s2 = zero4;
+#pragma unroll
+  for (int u = 0; u < CPT; ++u) {
+    const int c = grp + u * LV_GROUPS;
+    const float gc = g[c];
+    if (ok) { xc[u].x -= mean.x; xc[u].y -= mean.y; xc[u].z -= mean.z; xc[u].w -= mean.w; }
+    const float4 dyg = make_float4(d[u].x * gc, d[u].y * gc, d[u].z * gc, d[u].w * gc);
+    s1.x += dyg.x; s1.y += dyg.y; s1.z += dyg.z; s1.w += dyg.w;
+    s2.x += dyg.x * xc[u].x; s2.y += dyg.y * xc[u].y; s2.z += dyg.z * xc[u].z; s2.w += dyg.w * xc[u].w;
+    // dg / db of channel c over the block's 32 positions: the lane's four, then the 8 lanes of the channel group
+    float a = ((d[u].x * xc[u].x * r.x + d[u].y * xc[u].y * r.y) + d[u].z * xc[u].z * r.z) + d[u].w * xc[u].w * r.w;
+    float bsum = ((d[u].x + d[u].y) + d[u].z) + d[u].w;
+#pragma unroll
+    for (int off = LV_PL / 2; off > 0; off >>= 1) {
+      a += __shfl_xor(a, off, 64);
+      bsum += __shfl_xor(bsum, off, 64);
+    }
+    if (pl == 0) {
+      pg[(long long)blockIdx.x * prow + c] = a;
+      pb[(long long)blockIdx.x * prow + c] = bsum;
+    }
+  }
+  // per-position sums over the channels: the wave's 8 channel groups by shuffles (lanes 8 apart), the 8 waves through LDS
+#pragma unroll
+  for (int off = LV_PL; off < 64; off <<= 1) {
+    s1.x += __shfl_xor(s1.x, off, 64); s1.y += __shfl_xor(s1.y, off, 64); s1.z += __shfl_xor(s1.z, off, 64); s1.w += __shfl_xor(s1.w, off, 64);
+    s2.x += __shfl_xor(s2.x, off, 64); s2.y += __shfl_xor(s2.y, off, 64); s2.z += __shfl_xor(s2.z, off, 64); s2.w += __shfl_xor(s2.w, off, 64);
+  }
+  if ((threadIdx.x & 63) < LV_PL) {
+    *reinterpret_cast<float4*>(&part[0][wave][4 * pl]) = s1;
+    *reinterpret_cast<float4*>(&part[1][wave][4 * pl]) = s2;
+  }
+  __syncthreads();
+  if (!ok) return;
+  float4 t1 = zero4, t2 = zero4;
+#pragma unroll
+  for (int w = 0; w < LV_THREADS / 64; ++w) {
+    const float4 a1 = *reinterpret_cast<const float4*>(&part[0][w][4 * pl]), a2 = *reinterpret_cast<const float4*>(&part[1][w][4 * pl]);
+    t1.x += a1.x; t1.y += a1.y; t1.z += a1.z; t1.w += a1.w;
+    t2.x += a2.x; t2.y += a2.y; t2.z += a2.z; t2.w += a2.w;
+  }
+  const float inv = 1.f / (float)Cc;
+  const float4 m1 = make_float4(t1.x * inv, t1.y * inv, t1.z * inv, t1.w * inv);
+  float4 k2;
+  {
+    const float sx = 1.f / r.x - eps, sy = 1.f / r.y - eps, sz = 1.f / r.z - eps, sw = 1.f / r.w - eps;
+    k2.x = sx > 0.f ? r.x * r.x / sx * (t2.x * inv) : 0.f;
+    k2.y = sy > 0.f ? r.y * r.y / sy * (t2.y * inv) : 0.f;
+    k2.z = sz > 0.f ? r.z * r.z / sz * (t2.z * inv) : 0.f;
+    k2.w = sw > 0.f ? r.w * r.w / sw * (t2.w * inv) : 0.f;
+  }
+  constexpr int AB = CPT < 2 ? CPT : 2;  // `add` quads fetched per batch
+#pragma unroll
+  for (int u0 = 0; u0 < CPT; u0 += AB) {
+    float4 av[AB];
+#pragma unroll
+    for (int u = 0; u < AB; ++u) {
+      av[u] = zero4;
+      if (add != nullptr) av[u] = *reinterpret_cast<const float4*>(add + (long long)(grp + (u0 + u) * LV_GROUPS) * N + n);
+    }
+#pragma unroll
+    for (int u = 0; u < AB; ++u) {
+      const int cc = grp + (u0 + u) * LV_GROUPS;
+      const float gc = g[cc];
+      const float4 dd = d[u0 + u], xx = xc[u0 + u];
+      *reinterpret_cast<float4*>(dx + (long long)cc * N + n) =
+          make_float4(r.x * (dd.x * gc - m1.x) - k2.x * xx.x + av[u].x, r.y * (dd.y * gc - m1.y) - k2.y * xx.y + av[u].y,
+                      r.z * (dd.z * gc - m1.z) - k2.z * xx.z + av[u].z, r.w * (dd.w * gc - m1.w) - k2.w * xx.w + av[u].w);
+    }
+  }
+}
+
+static bool launch_ln_bwd_v4(const float* dy, const float* x, const float* g, const float* mu, const float* rs, float* dx, float* pg, float* pb, int C,
+                             long long N, float eps, const float* add, long long prow, hipStream_t st) {
+  static_assert(LV_POS == LN_COLS, "the partial-sum matrices have one row per LN_COLS positions (advhip_chan_layernorm_bwd_partial_rows)");
+  if (N % 4 != 0 || (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)mu | (uintptr_t)rs | (uintptr_t)add) & 15) != 0) return false;
+  const dim3 grid((unsigned)((N + LV_POS - 1) / LV_POS)), block(LV_THREADS);
+  switch (C) {
+    case 1 * LV_GROUPS: hipLaunchKernelGGL(chan_layernorm_bwd_v4_kernel<1>, grid, block, 0, st, dy, x, g, mu, rs, dx, pg, pb, N, eps, add, prow); return true;
+    case 2 * LV_GROUPS: hipLaunchKernelGGL(chan_layernorm_bwd_v4_kernel<2>, grid, block, 0, st, dy, x, g, mu, rs, dx, pg, pb, N, eps, add, prow); return true;
+    case 16 * LV_GROUPS: hipLaunchKernelGGL(chan_layernorm_bwd_v4_kernel<16>, grid, block, 0, st, dy, x, g, mu, rs, dx, pg, pb, N, eps, add, prow); return true;
+    default: return false;
+  }
+}
+
 // out[c, b, t] = bias[c % H] + sum_j w[c % H][j] * v[c, b, t + j - K/2]   (zero outside [0, T)); one thread per element
 template <int K>
 __global__ __launch_bounds__(256) void dwconv_t_fwd_kernel(const float* __restrict__ v, const float* __restrict__ w,
@@ -241,6 +366,88 @@ __global__ __launch_bounds__(256) void dwconv_t_bwd_kernel(const float* __restri
     partial[(((long long)(c / H) * chunks + chunk) * H + h) * (K + 1) + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// The same two kernels with a thread owning FOUR consecutive t of a row (T % 4 == 0, 16-byte accesses, one 64-bit division per
+// quad instead of three per element): the window v[t - K/2 .. t + 3 + K/2] is the quad, its left and its right neighbour quad
+// (zero outside the row).  Same sums per output; the per-block partial sums of the backward associate differently (1e-7).
+__device__ __forceinline__ void dw_window(const float* __restrict__ p, long long e, int t, int T, float (&win)[12]) {
+  const float4 c = *reinterpret_cast<const float4*>(p + e);
+  float4 l = make_float4(0.f, 0.f, 0.f, 0.f), r = l;
+  if (t > 0) l = *reinterpret_cast<const float4*>(p + e - 4);
+  if (t + 4 < T) r = *reinterpret_cast<const float4*>(p + e + 4);
+  win[0] = l.x; win[1] = l.y; win[2] = l.z; win[3] = l.w;
+  win[4] = c.x; win[5] = c.y; win[6] = c.z; win[7] = c.w;
+  win[8] = r.x; win[9] = r.y; win[10] = r.z; win[11] = r.w;
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_t_fwd_v4_kernel(const float* __restrict__ v, const float* __restrict__ w, const float* __restrict__ bias,
+                                                              float* __restrict__ out, int H, int T, long long rows_per_c, long long total4) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+    const long long e = i * 4;
+    const int t = (int)(e % T);
+    const int h = (int)((e / (rows_per_c * T)) % H);
+    float win[12], wk[K];
+    dw_window(v, e, t, T, win);
+#pragma unroll
+    for (int j = 0; j < K; ++j) wk[j] = w[h * K + j];
+    const float b = bias[h];
+    float o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float acc = b;
+#pragma unroll
+      for (int j = 0; j < K; ++j) acc += wk[j] * win[4 + q + j - K / 2];  // (zero outside the row: the same sum as the scalar kernel's taps in range)
+      o[q] = acc;
+    }
+    *reinterpret_cast<float4*>(out + e) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_t_bwd_v4_kernel(const float* __restrict__ dout, const float* __restrict__ v, const float* __restrict__ w,
+                                                              float* __restrict__ dv, float* __restrict__ partial, int H, int T, long long per_c,
+                                                              int chunks) {
+  __shared__ float red[4][K + 1];
+  const int c = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  const int h = c % H;
+  const long long lo = (per_c * chunk) / chunks, hi = (per_c * (chunk + 1)) / chunks;  // whole rows: multiples of T, hence of 4
+  float acc[K + 1], wk[K];
+#pragma unroll
+  for (int j = 0; j <= K; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < K; ++j) wk[j] = w[h * K + j];
+  for (long long e = lo + 4ll * threadIdx.x; e < hi; e += 1024) {
+    const long long i = (long long)c * per_c + e;
+    const int t = (int)(e % T);
+    float dw[12], vw[12], g[4];
+    dw_window(dout, i, t, T, dw);
+    dw_window(v, i, t, T, vw);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float gq = 0.f;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        acc[j] += dw[4 + q] * vw[4 + q + j - K / 2];  // tap j of output t + q touched v[t + q + j - K/2]
+        gq += wk[j] * dw[4 + q - j + K / 2];          // v[t + q] was touched with tap j by output t + q - j + K/2
+      }
+      acc[K] += dw[4 + q];
+      g[q] = gq;
+    }
+    *reinterpret_cast<float4*>(dv + i) = make_float4(g[0], g[1], g[2], g[3]);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j <= K; ++j) {
+    float a = acc[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    if (lane == 0) red[wv][j] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x <= K)
+    partial[(((long long)(c / H) * chunks + chunk) * H + h) * (K + 1) + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 // The rows a k = 3, padding 1 temporal conv contracts with, for its weight gradient dW = dY . U^T:
 //   U[(c * 3 + j), r, t] = x[c, r, t + j - 1]  (0 outside [0, T)), x (C, rows, T) -> U (3 C, rows, T), tap-minor like the weights.
 // One thread per float4 of x's row: reads it (+ one neighbour on each side) and writes the three shifted copies.
@@ -268,6 +475,20 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   if (lane == 0) red[w] = v;
   __syncthreads();
   return red[0] + red[1] + red[2] + red[3];
+}
+
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) t += red[i];
+  return t;
 }
 
 // training mode: batch statistics per channel (one block per channel row); y = (x - mean) * rstd * gamma + beta;
@@ -302,6 +523,69 @@ __global__ __launch_bounds__(256) void bn_rows_fwd_kernel(const float* __restric
       run_var[c] = (1.f - momentum) * run_var[c] + momentum * (var * ((float)N / (float)(N > 1 ? N - 1 : 1)));
     }
   }
+}
+
+// The same forward for rows of up to NT x 4 x BQ floats (N % 4 == 0): the thread's share of the row -- BQ float4 -- stays in
+// registers between the mean, the variance and the output: ONE read of x (the kernel above: three).  NT = 1 024 threads for the
+// narrow layers (C = 128 rows are 128 blocks on 256 CUs: the block's own width is what parallelism there is).
+template <int NT, int BQ>
+__global__ __launch_bounds__(NT) void bn_rows_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ var_out,
+                                                              long long N, float eps, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                              float momentum) {
+  __shared__ float red[NT / 64];
+  const int c = blockIdx.x;
+  const float* xr = x + (long long)c * N;
+  const long long nq = N / 4;
+  float4 v[BQ];
+#pragma unroll
+  for (int u = 0; u < BQ; ++u) {
+    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long q = threadIdx.x + (long long)NT * u;
+    if (q < nq) v[u] = *reinterpret_cast<const float4*>(xr + 4 * q);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < BQ; ++u) s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+  const float mean = block_sum<NT>(s, red) / (float)N;
+  float q2 = 0.f;
+#pragma unroll
+  for (int u = 0; u < BQ; ++u) {
+    if (threadIdx.x + (long long)NT * u < nq) {
+      const float d0 = v[u].x - mean, d1 = v[u].y - mean, d2 = v[u].z - mean, d3 = v[u].w - mean;
+      q2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  }
+  const float var = block_sum<NT>(q2, red) / (float)N;
+  const float sc = gamma[c] * rsqrtf(var + eps), sh = beta[c] - mean * sc;
+  float* yr = y + (long long)c * N;
+#pragma unroll
+  for (int u = 0; u < BQ; ++u) {
+    const long long q = threadIdx.x + (long long)NT * u;
+    if (q < nq) *reinterpret_cast<float4*>(yr + 4 * q) = make_float4(v[u].x * sc + sh, v[u].y * sc + sh, v[u].z * sc + sh, v[u].w * sc + sh);
+  }
+  if (threadIdx.x == 0) {
+    mean_out[c] = mean;
+    var_out[c] = var;
+    if (run_mean != nullptr) {
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * (var * ((float)N / (float)(N > 1 ? N - 1 : 1)));
+    }
+  }
+}
+
+static void launch_bn_rows_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* var, int C, long long N, float eps,
+                               float* run_mean, float* run_var, float momentum, hipStream_t st) {
+  const bool vec = N % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+  const dim3 grid((unsigned)C);
+  if (vec && C < 512 && N <= 1024 * 4 * 4)
+    hipLaunchKernelGGL((bn_rows_fwd_reg_kernel<1024, 4>), grid, dim3(1024), 0, st, x, gamma, beta, y, mean, var, N, eps, run_mean, run_var, momentum);
+  else if (vec && N <= 256 * 4 * 4)
+    hipLaunchKernelGGL((bn_rows_fwd_reg_kernel<256, 4>), grid, dim3(256), 0, st, x, gamma, beta, y, mean, var, N, eps, run_mean, run_var, momentum);
+  else if (vec && N <= 256 * 4 * 12)
+    hipLaunchKernelGGL((bn_rows_fwd_reg_kernel<256, 12>), grid, dim3(256), 0, st, x, gamma, beta, y, mean, var, N, eps, run_mean, run_var, momentum);
+  else
+    hipLaunchKernelGGL(bn_rows_fwd_kernel, grid, dim3(256), 0, st, x, gamma, beta, y, mean, var, N, eps, run_mean, run_var, momentum);
 }
 
 // dx = gamma * rstd * (dy - mean(dy) - xhat * mean(dy * xhat)),  dgamma = sum dy * xhat,  dbeta = sum dy
@@ -390,6 +674,72 @@ __global__ __launch_bounds__(256) void colsum_group_kernel(const ColsumGroupArgs
   while (i + 1 < ga.n && (int)blockIdx.x >= ga.it[i + 1].block_begin) ++i;
   const ColsumGroupItem& t = ga.it[i];
   colsum_body(t.src, t.dst, t.rows, t.cols, (int)blockIdx.x - t.block_begin, t.period);
+}
+
+// bn_rows_bwd_kernel with the thread's share of dy and x resident in registers (rows of up to NT x 4 x BQ floats, N % 4 == 0): one
+// read of each instead of two; NT = 1 024 for the narrow layers, as in the forward.
+template <int NT, int BQ>
+__global__ __launch_bounds__(NT) void bn_rows_bwd_reg_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ mean, const float* __restrict__ var, float* __restrict__ dx,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, long long N, float eps,
+                                                             const float* __restrict__ add) {
+  __shared__ float red[NT / 64];
+  const int c = blockIdx.x;
+  const float* xr = x + (long long)c * N;
+  const float* dr = dy + (long long)c * N;
+  const long long nq = N / 4;
+  const float mu = mean[c], rstd = rsqrtf(var[c] + eps);
+  float4 d[BQ], h[BQ];
+#pragma unroll
+  for (int u = 0; u < BQ; ++u) {
+    d[u] = h[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long q = threadIdx.x + (long long)NT * u;
+    if (q < nq) {
+      d[u] = *reinterpret_cast<const float4*>(dr + 4 * q);
+      h[u] = *reinterpret_cast<const float4*>(xr + 4 * q);
+    }
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int u = 0; u < BQ; ++u) {
+    if (threadIdx.x + (long long)NT * u < nq) {
+      h[u] = make_float4((h[u].x - mu) * rstd, (h[u].y - mu) * rstd, (h[u].z - mu) * rstd, (h[u].w - mu) * rstd);
+      s1 += (d[u].x + d[u].y) + (d[u].z + d[u].w);
+      s2 += (d[u].x * h[u].x + d[u].y * h[u].y) + (d[u].z * h[u].z + d[u].w * h[u].w);
+    }
+  }
+  const float sum_dy = block_sum<NT>(s1, red);
+  const float sum_dyx = block_sum<NT>(s2, red);
+  const float k = gamma[c] * rstd, m1 = sum_dy / (float)N, m2 = sum_dyx / (float)N;
+  float* o = dx + (long long)c * N;
+#pragma unroll
+  for (int u = 0; u < BQ; ++u) {
+    const long long q = threadIdx.x + (long long)NT * u;
+    if (q < nq) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (add != nullptr) a = *reinterpret_cast<const float4*>(add + (long long)c * N + 4 * q);
+      *reinterpret_cast<float4*>(o + 4 * q) = make_float4(k * (d[u].x - m1 - h[u].x * m2) + a.x, k * (d[u].y - m1 - h[u].y * m2) + a.y,
+                                                          k * (d[u].z - m1 - h[u].z * m2) + a.z, k * (d[u].w - m1 - h[u].w * m2) + a.w);
+    }
+  }
+  if (threadIdx.x == 0) {
+    dgamma[c] = sum_dyx;
+    dbeta[c] = sum_dy;
+  }
+}
+
+static void launch_bn_rows_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* var, float* dx, float* dgamma,
+                               float* dbeta, int C, long long N, float eps, const float* add, hipStream_t st) {
+  const bool vec = N % 4 == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)add) & 15) == 0;
+  const dim3 grid((unsigned)C);
+  if (vec && C < 512 && N <= 1024 * 4 * 4)
+    hipLaunchKernelGGL((bn_rows_bwd_reg_kernel<1024, 4>), grid, dim3(1024), 0, st, dy, x, gamma, mean, var, dx, dgamma, dbeta, N, eps, add);
+  else if (vec && N <= 256 * 4 * 4)
+    hipLaunchKernelGGL((bn_rows_bwd_reg_kernel<256, 4>), grid, dim3(256), 0, st, dy, x, gamma, mean, var, dx, dgamma, dbeta, N, eps, add);
+  else if (vec && N <= 256 * 4 * 12)
+    hipLaunchKernelGGL((bn_rows_bwd_reg_kernel<256, 12>), grid, dim3(256), 0, st, dy, x, gamma, mean, var, dx, dgamma, dbeta, N, eps, add);
+  else
+    hipLaunchKernelGGL(bn_rows_bwd_kernel, grid, dim3(256), 0, st, dy, x, gamma, mean, var, dx, dgamma, dbeta, N, eps, add);
 }
 
 // ---- the scorer's head on the body's layout (modeling_mgfn.py:387-389: permute -> nn.LayerNorm(C) -> Linear(C, 1) -> sigmoid) ----
@@ -538,6 +888,178 @@ __global__ __launch_bounds__(LN_THREADS) void head_ln_fc_bwd_kernel(const float*
       const float dy = tile[p][cl] + dl * w[c];
       dx[o] = r * (dy * g[c] - m1 - xh * m2);
     }
+  }
+}
+
+// ---- the head, re-blocked like chan_layernorm_bwd_v4_kernel (a lane owns four consecutive positions and C / 64 channels, every
+// value of y resident in registers: ONE read of y in 16-byte accesses; the (C, N) <-> (N, C) transposition through a 32 x 64 LDS tile
+// per 64-channel chunk, rows written / read as 16-byte pieces).  C = 64 * CPT, N % 4 == 0, 16-byte aligned operands.
+constexpr int HV_PAD = LV_GROUPS + 4;  // tile row pitch in floats (16-byte aligned rows)
+
+// the lane's four per-position partial sums, over the wave's 8 channel groups (lanes 8 apart) and the block's 8 waves
+__device__ __forceinline__ float4 lv_position_sum(float4 v, float (*part)[LV_POS], int pl, int wave) {
+#pragma unroll
+  for (int off = LV_PL; off < 64; off <<= 1) {
+    v.x += __shfl_xor(v.x, off, 64); v.y += __shfl_xor(v.y, off, 64); v.z += __shfl_xor(v.z, off, 64); v.w += __shfl_xor(v.w, off, 64);
+  }
+  __syncthreads();  // (part may still be read from a previous call)
+  if ((threadIdx.x & 63) < LV_PL) *reinterpret_cast<float4*>(&part[wave][4 * pl]) = v;
+  __syncthreads();
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int w = 0; w < LV_THREADS / 64; ++w) {
+    const float4 a = *reinterpret_cast<const float4*>(&part[w][4 * pl]);
+    t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+  }
+  return t;
+}
+
+template <int CPT>
+__global__ __launch_bounds__(LV_THREADS) void head_ln_fc_fwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                                       const float* __restrict__ w, const float* __restrict__ b0, float* __restrict__ xn,
+                                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                                       float* __restrict__ score, long long N, float eps) {
+  constexpr int Cc = CPT * LV_GROUPS;
+  __shared__ float part[LV_THREADS / 64][LV_POS];
+  __shared__ __attribute__((aligned(16))) float tile[LV_POS][HV_PAD];
+  const int pl = threadIdx.x % LV_PL, grp = threadIdx.x / LV_PL, wave = threadIdx.x >> 6;
+  const long long n0 = blockIdx.x * (long long)LV_POS, n = n0 + 4 * pl;
+  const bool ok = n < N;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 v[CPT], x0 = zero4;
+#pragma unroll
+  for (int u = 0; u < CPT; ++u) v[u] = zero4;
+  if (ok) {
+    x0 = *reinterpret_cast<const float4*>(x + n);  // channel 0: the shift of the one-pass statistics (as ln_stats)
+    const float* xp = x + (long long)grp * N + n;
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) v[u] = *reinterpret_cast<const float4*>(xp + (long long)u * LV_GROUPS * N);
+  }
+  float4 s1 = zero4, s2 = zero4;
+#pragma unroll
+  for (int u = 0; u < CPT; ++u) {
+    const float4 d = make_float4(v[u].x - x0.x, v[u].y - x0.y, v[u].z - x0.z, v[u].w - x0.w);
+    s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+    s2.x += d.x * d.x; s2.y += d.y * d.y; s2.z += d.z * d.z; s2.w += d.w * d.w;
+  }
+  const float4 t1 = lv_position_sum(s1, part, pl, wave), t2 = lv_position_sum(s2, part, pl, wave);
+  const float inv = 1.f / (float)Cc;
+  const float4 m1 = make_float4(t1.x * inv, t1.y * inv, t1.z * inv, t1.w * inv);
+  const float4 mean = make_float4(x0.x + m1.x, x0.y + m1.y, x0.z + m1.z, x0.w + m1.w);
+  const float4 r = make_float4(rsqrtf(fmaxf(t2.x * inv - m1.x * m1.x, 0.f) + eps), rsqrtf(fmaxf(t2.y * inv - m1.y * m1.y, 0.f) + eps),
+                               rsqrtf(fmaxf(t2.z * inv - m1.z * m1.z, 0.f) + eps), rsqrtf(fmaxf(t2.w * inv - m1.w * m1.w, 0.f) + eps));
+  if (ok && grp == 0) {
+    *reinterpret_cast<float4*>(mean_out + n) = mean;
+    *reinterpret_cast<float4*>(rstd_out + n) = r;
+  }
+  float4 dot = zero4;
+  const int orow = threadIdx.x / 16, ocol = (threadIdx.x % 16) * 4;  // this thread's 16-byte piece of the 32 x 64 tile on the way out
+#pragma unroll
+  for (int u = 0; u < CPT; ++u) {
+    const int c = grp + u * LV_GROUPS;
+    const float gc = g[c], bc = b[c], wc = w[c];
+    const float4 o = make_float4((v[u].x - mean.x) * r.x * gc + bc, (v[u].y - mean.y) * r.y * gc + bc, (v[u].z - mean.z) * r.z * gc + bc,
+                                 (v[u].w - mean.w) * r.w * gc + bc);
+    if (ok) { dot.x += o.x * wc; dot.y += o.y * wc; dot.z += o.z * wc; dot.w += o.w * wc; }
+    __syncthreads();  // (the previous chunk's readers are done)
+    tile[4 * pl + 0][grp] = o.x;
+    tile[4 * pl + 1][grp] = o.y;
+    tile[4 * pl + 2][grp] = o.z;
+    tile[4 * pl + 3][grp] = o.w;
+    __syncthreads();
+    if (n0 + orow < N) *reinterpret_cast<float4*>(xn + (n0 + orow) * Cc + u * LV_GROUPS + ocol) = *reinterpret_cast<const float4*>(&tile[orow][ocol]);
+  }
+  const float4 z = lv_position_sum(dot, part, pl, wave);
+  if (ok && grp == 0) {
+    const float bb = b0[0];
+    *reinterpret_cast<float4*>(score + n) = make_float4(1.f / (1.f + expf(-(z.x + bb))), 1.f / (1.f + expf(-(z.y + bb))), 1.f / (1.f + expf(-(z.z + bb))),
+                                                        1.f / (1.f + expf(-(z.w + bb))));
+  }
+}
+
+template <int CPT>
+__global__ __launch_bounds__(LV_THREADS) void head_ln_fc_bwd_v4_kernel(const float* __restrict__ dxn, const float* __restrict__ dscore,
+                                                                       const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                                       const float* __restrict__ w, const float* __restrict__ mean_in,
+                                                                       const float* __restrict__ rstd_in, const float* __restrict__ score,
+                                                                       float* __restrict__ dx, float* __restrict__ partial, long long N) {
+  constexpr int Cc = CPT * LV_GROUPS;
+  __shared__ float part[LV_THREADS / 64][LV_POS];
+  __shared__ __attribute__((aligned(16))) float tile[LV_POS][HV_PAD];
+  const int pl = threadIdx.x % LV_PL, grp = threadIdx.x / LV_PL, wave = threadIdx.x >> 6;
+  const long long n0 = blockIdx.x * (long long)LV_POS, n = n0 + 4 * pl;
+  const bool ok = n < N;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 mean = zero4, r = zero4, dl = zero4, xh[CPT], dy[CPT];
+#pragma unroll
+  for (int u = 0; u < CPT; ++u) xh[u] = dy[u] = zero4;
+  if (ok) {
+    mean = *reinterpret_cast<const float4*>(mean_in + n);
+    r = *reinterpret_cast<const float4*>(rstd_in + n);
+    if (dscore != nullptr) {
+      const float4 sg = *reinterpret_cast<const float4*>(score + n), ds = *reinterpret_cast<const float4*>(dscore + n);
+      dl = make_float4(ds.x * sg.x * (1.f - sg.x), ds.y * sg.y * (1.f - sg.y), ds.z * sg.z * (1.f - sg.z), ds.w * sg.w * (1.f - sg.w));
+    }
+    const float* xp = x + (long long)grp * N + n;
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) xh[u] = *reinterpret_cast<const float4*>(xp + (long long)u * LV_GROUPS * N);
+  }
+  float* prow = partial + (long long)blockIdx.x * (3 * Cc + 1);
+  const int irow = threadIdx.x / 16, icol = (threadIdx.x % 16) * 4;  // this thread's 16-byte piece of the 32 x 64 tile on the way in
+  float4 s1 = zero4, s2 = zero4;
+#pragma unroll
+  for (int u = 0; u < CPT; ++u) {
+    const int c = grp + u * LV_GROUPS;
+    const float gc = g[c], bc = b[c], wc = w[c];
+    float4 din = zero4;
+    if (dxn != nullptr) {  // d_xn (N, C) -> the lane's (channel, four positions) through the tile
+      __syncthreads();
+      float4 piece = zero4;
+      if (n0 + irow < N) piece = *reinterpret_cast<const float4*>(dxn + (n0 + irow) * Cc + u * LV_GROUPS + icol);
+      *reinterpret_cast<float4*>(&tile[irow][icol]) = piece;
+      __syncthreads();
+      din = make_float4(tile[4 * pl + 0][grp], tile[4 * pl + 1][grp], tile[4 * pl + 2][grp], tile[4 * pl + 3][grp]);
+    }
+    float4 h = zero4, d = zero4, cw4 = zero4;
+    if (ok) {
+      h = make_float4((xh[u].x - mean.x) * r.x, (xh[u].y - mean.y) * r.y, (xh[u].z - mean.z) * r.z, (xh[u].w - mean.w) * r.w);
+      d = make_float4(din.x + dl.x * wc, din.y + dl.y * wc, din.z + dl.z * wc, din.w + dl.w * wc);
+      cw4 = make_float4(dl.x * (h.x * gc + bc), dl.y * (h.y * gc + bc), dl.z * (h.z * gc + bc), dl.w * (h.w * gc + bc));
+    }
+    xh[u] = h;
+    dy[u] = d;
+    s1.x += d.x * gc; s1.y += d.y * gc; s1.z += d.z * gc; s1.w += d.w * gc;
+    s2.x += d.x * gc * h.x; s2.y += d.y * gc * h.y; s2.z += d.z * gc * h.z; s2.w += d.w * gc * h.w;
+    float a = ((d.x * h.x + d.y * h.y) + d.z * h.z) + d.w * h.w, bs = ((d.x + d.y) + d.z) + d.w, cw = ((cw4.x + cw4.y) + cw4.z) + cw4.w;
+#pragma unroll
+    for (int off = LV_PL / 2; off > 0; off >>= 1) {
+      a += __shfl_xor(a, off, 64);
+      bs += __shfl_xor(bs, off, 64);
+      cw += __shfl_xor(cw, off, 64);
+    }
+    if (pl == 0) {
+      prow[c] = a;
+      prow[Cc + c] = bs;
+      prow[2 * Cc + c] = cw;
+    }
+  }
+  if (grp == 0) {  // db0: the block's sum of dlogit
+    float t = ((dl.x + dl.y) + dl.z) + dl.w;
+#pragma unroll
+    for (int off = LV_PL / 2; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    if (pl == 0) prow[3 * Cc] = t;
+  }
+  const float4 t1 = lv_position_sum(s1, part, pl, wave), t2 = lv_position_sum(s2, part, pl, wave);
+  if (!ok) return;
+  const float inv = 1.f / (float)Cc;
+  const float4 m1 = make_float4(t1.x * inv, t1.y * inv, t1.z * inv, t1.w * inv), m2 = make_float4(t2.x * inv, t2.y * inv, t2.z * inv, t2.w * inv);
+  float* dxp = dx + (long long)grp * N + n;
+#pragma unroll
+  for (int u = 0; u < CPT; ++u) {
+    const float gc = g[grp + u * LV_GROUPS];
+    *reinterpret_cast<float4*>(dxp + (long long)u * LV_GROUPS * N) =
+        make_float4(r.x * (dy[u].x * gc - m1.x - xh[u].x * m2.x), r.y * (dy[u].y * gc - m1.y - xh[u].y * m2.y),
+                    r.z * (dy[u].z * gc - m1.z - xh[u].z * m2.z), r.w * (dy[u].w * gc - m1.w - xh[u].w * m2.w));
   }
 }
 
@@ -934,15 +1456,16 @@ __global__ __launch_bounds__(256) void amp_combine_fwd_kernel(const float* __res
 
 // backward: dz[j][o][p] = dy[o][p - j + 1] inside the row, else 0; one block per output channel o also reduces, in a fixed order,
 // d_bias[o] = sum dy, d_bm[o] = ratio * sum dy, d_wm[o][j] = ratio * sum dy[o][p] * mag[p + j - 1]
-__global__ __launch_bounds__(256) void amp_combine_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ mag, long long mag_stride,
+constexpr int AMPB_THREADS = 1024;  // one block per output channel (64 of them): the block's width is the parallelism there is
+__global__ __launch_bounds__(AMPB_THREADS) void amp_combine_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ mag, long long mag_stride,
                                                               float ratio, float* __restrict__ dz, float* __restrict__ d_bias,
                                                               float* __restrict__ d_wm, float* __restrict__ d_bm, int O, long long rows, int T) {
-  __shared__ float red[4][256];
+  __shared__ float red[4][AMPB_THREADS];
   const int o = blockIdx.x;
   const long long n = rows * T;
   const float* g = dy + (long long)o * n;
   float s = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  for (long long p = threadIdx.x; p < n; p += 256) {
+  for (long long p = threadIdx.x; p < n; p += AMPB_THREADS) {
     const int t = (int)(p % T);
     const float v = g[p];
     dz[((long long)O + o) * n + p] = v;
@@ -955,7 +1478,7 @@ __global__ __launch_bounds__(256) void amp_combine_bwd_kernel(const float* __res
   }
   red[0][threadIdx.x] = s; red[1][threadIdx.x] = s0; red[2][threadIdx.x] = s1; red[3][threadIdx.x] = s2;
   __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
+  for (int w = AMPB_THREADS / 2; w > 0; w >>= 1) {
     if ((int)threadIdx.x < w) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + w];
@@ -977,8 +1500,7 @@ using namespace advhip;
 extern "C" int advhip_bn_rows_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* var,
                                       int32_t C, int64_t N, float eps, void* stream) {
   ADVHIP_REQUIRE(x && gamma && beta && y && mean && var && C > 0 && N > 0, "bn_rows_fwd: bad arguments");
-  hipLaunchKernelGGL(bn_rows_fwd_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, var, (long long)N, eps,
-                     (float*)nullptr, (float*)nullptr, 0.f);
+  launch_bn_rows_fwd(x, gamma, beta, y, mean, var, C, (long long)N, eps, nullptr, nullptr, 0.f, (hipStream_t)stream);
   return check_launch("bn_rows_fwd");
 }
 
@@ -987,16 +1509,14 @@ extern "C" int advhip_bn_rows_fwd_running_f32(const float* x, const float* gamma
                                               void* stream) {
   ADVHIP_REQUIRE(x && gamma && beta && y && mean && var && C > 0 && N > 0, "bn_rows_fwd_running: bad arguments");
   ADVHIP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_rows_fwd_running: running_mean and running_var come together");
-  hipLaunchKernelGGL(bn_rows_fwd_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, var, (long long)N, eps,
-                     running_mean, running_var, momentum);
+  launch_bn_rows_fwd(x, gamma, beta, y, mean, var, C, (long long)N, eps, running_mean, running_var, momentum, (hipStream_t)stream);
   return check_launch("bn_rows_fwd_running");
 }
 
 extern "C" int advhip_bn_rows_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* var,
                                       float* dx, float* dgamma, float* dbeta, int32_t C, int64_t N, float eps, void* stream) {
   ADVHIP_REQUIRE(dy && x && gamma && mean && var && dx && dgamma && dbeta && C > 0 && N > 0, "bn_rows_bwd: bad arguments");
-  hipLaunchKernelGGL(bn_rows_bwd_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, var, dx, dgamma, dbeta,
-                     (long long)N, eps, (const float*)nullptr);
+  launch_bn_rows_bwd(dy, x, gamma, mean, var, dx, dgamma, dbeta, C, (long long)N, eps, nullptr, (hipStream_t)stream);
   return check_launch("bn_rows_bwd");
 }
 
@@ -1004,8 +1524,7 @@ extern "C" int advhip_bn_rows_bwd_add_f32(const float* dy, const float* x, const
                                           const float* add, float* dx, float* dgamma, float* dbeta, int32_t C, int64_t N, float eps,
                                           void* stream) {
   ADVHIP_REQUIRE(dy && x && gamma && mean && var && dx && dgamma && dbeta && C > 0 && N > 0, "bn_rows_bwd_add: bad arguments");
-  hipLaunchKernelGGL(bn_rows_bwd_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, var, dx, dgamma, dbeta,
-                     (long long)N, eps, add);
+  launch_bn_rows_bwd(dy, x, gamma, mean, var, dx, dgamma, dbeta, C, (long long)N, eps, add, (hipStream_t)stream);
   return check_launch("bn_rows_bwd_add");
 }
 
@@ -1035,8 +1554,9 @@ extern "C" int advhip_chan_layernorm_bwd_f32(const float* dy, const float* x, co
   ADVHIP_REQUIRE(dy && x && g && mu && rs && dx && dg_partial && db_partial && C > 0 && N > 0, "chan_layernorm_bwd: bad arguments");
   const long long blocks = (N + LN_COLS - 1) / LN_COLS;
   ADVHIP_REQUIRE(blocks < (1ll << 31), "chan_layernorm_bwd: too many positions");
-  hipLaunchKernelGGL(chan_layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, dy, x, g, mu, rs, dx,
-                     dg_partial, db_partial, C, (long long)N, eps, (const float*)nullptr, (long long)C);
+  if (!launch_ln_bwd_v4(dy, x, g, mu, rs, dx, dg_partial, db_partial, C, (long long)N, eps, nullptr, (long long)C, (hipStream_t)stream))
+    hipLaunchKernelGGL(chan_layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, dy, x, g, mu, rs, dx,
+                       dg_partial, db_partial, C, (long long)N, eps, (const float*)nullptr, (long long)C);
   return check_launch("chan_layernorm_bwd");
 }
 
@@ -1046,8 +1566,9 @@ extern "C" int advhip_chan_layernorm_bwd_add_f32(const float* dy, const float* x
   ADVHIP_REQUIRE(dy && x && g && mu && rs && dx && dgb_partial && C > 0 && N > 0, "chan_layernorm_bwd_add: bad arguments");
   const long long blocks = (N + LN_COLS - 1) / LN_COLS;
   ADVHIP_REQUIRE(blocks < (1ll << 31), "chan_layernorm_bwd_add: too many positions");
-  hipLaunchKernelGGL(chan_layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, dy, x, g, mu, rs, dx,
-                     dgb_partial, dgb_partial + C, C, (long long)N, eps, add, 2ll * C);
+  if (!launch_ln_bwd_v4(dy, x, g, mu, rs, dx, dgb_partial, dgb_partial + C, C, (long long)N, eps, add, 2ll * C, (hipStream_t)stream))
+    hipLaunchKernelGGL(chan_layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, dy, x, g, mu, rs, dx,
+                       dgb_partial, dgb_partial + C, C, (long long)N, eps, add, 2ll * C);
   return check_launch("chan_layernorm_bwd_add");
 }
 
@@ -1066,6 +1587,12 @@ extern "C" int advhip_dwconv_t_fwd_f32(const float* v, const float* w, const flo
   ADVHIP_REQUIRE(K == 5 || K == 3, "dwconv_t: kernel size %d (3 and 5 are instantiated)", K);
   const long long total = (long long)C * rows * T;
   const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 32);
+  if (T % 4 == 0 && (((uintptr_t)v | (uintptr_t)out) & 15) == 0) {
+    const int grid4 = (int)std::min<long long>((total / 4 + 255) / 256, 256 * 32);
+    if (K == 5) hipLaunchKernelGGL(dwconv_t_fwd_v4_kernel<5>, dim3(grid4), dim3(256), 0, (hipStream_t)stream, v, w, bias, out, H, T, (long long)rows, total / 4);
+    else hipLaunchKernelGGL(dwconv_t_fwd_v4_kernel<3>, dim3(grid4), dim3(256), 0, (hipStream_t)stream, v, w, bias, out, H, T, (long long)rows, total / 4);
+    return check_launch("dwconv_t_fwd");
+  }
   if (K == 5) hipLaunchKernelGGL(dwconv_t_fwd_kernel<5>, dim3(grid), dim3(256), 0, (hipStream_t)stream, v, w, bias, out, H, T, (long long)rows, total);
   else hipLaunchKernelGGL(dwconv_t_fwd_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, v, w, bias, out, H, T, (long long)rows, total);
   return check_launch("dwconv_t_fwd");
@@ -1085,6 +1612,11 @@ extern "C" int advhip_dwconv_t_bwd_f32(const float* dout, const float* v, const 
   const int chunks = advhip_dwconv_t_bwd_chunks(C, rows);
   const long long per_c = (long long)rows * T;
   const dim3 grid((unsigned)((long long)C * chunks));
+  if (T % 4 == 0 && (((uintptr_t)v | (uintptr_t)dout | (uintptr_t)dv) & 15) == 0) {
+    if (K == 5) hipLaunchKernelGGL(dwconv_t_bwd_v4_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, dout, v, w, dv, partial, H, T, per_c, chunks);
+    else hipLaunchKernelGGL(dwconv_t_bwd_v4_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, dout, v, w, dv, partial, H, T, per_c, chunks);
+    return check_launch("dwconv_t_bwd");
+  }
   if (K == 5) hipLaunchKernelGGL(dwconv_t_bwd_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, dout, v, w, dv, partial, H, T, per_c, chunks);
   else hipLaunchKernelGGL(dwconv_t_bwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, dout, v, w, dv, partial, H, T, per_c, chunks);
   return check_launch("dwconv_t_bwd");
@@ -1152,8 +1684,14 @@ extern "C" int advhip_head_ln_fc_fwd_f32(const float* y, const float* ln_g, cons
   ADVHIP_REQUIRE(y && ln_g && ln_b && fc_w && fc_b && xn && mean && rstd && score && C > 0 && N > 0, "head_ln_fc_fwd: bad arguments");
   const long long blocks = (N + LN_COLS - 1) / LN_COLS;
   ADVHIP_REQUIRE(blocks < (1ll << 31), "head_ln_fc_fwd: too many positions");
-  hipLaunchKernelGGL(head_ln_fc_fwd_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, y, ln_g, ln_b, fc_w, fc_b, xn, mean, rstd,
-                     score, C, (long long)N, eps);
+  const bool v4 = C == 16 * LV_GROUPS && N % 4 == 0 &&
+                  (((uintptr_t)y | (uintptr_t)xn | (uintptr_t)mean | (uintptr_t)rstd | (uintptr_t)score) & 15) == 0;
+  if (v4)
+    hipLaunchKernelGGL(head_ln_fc_fwd_v4_kernel<16>, dim3((unsigned)blocks), dim3(LV_THREADS), 0, (hipStream_t)stream, y, ln_g, ln_b, fc_w, fc_b, xn, mean,
+                       rstd, score, (long long)N, eps);
+  else
+    hipLaunchKernelGGL(head_ln_fc_fwd_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, y, ln_g, ln_b, fc_w, fc_b, xn, mean, rstd,
+                       score, C, (long long)N, eps);
   return check_launch("head_ln_fc_fwd");
 }
 
@@ -1163,8 +1701,14 @@ extern "C" int advhip_head_ln_fc_bwd_f32(const float* d_xn, const float* d_score
   ADVHIP_REQUIRE(y && ln_g && ln_b && fc_w && mean && rstd && score && dy && partial && C > 0 && N > 0, "head_ln_fc_bwd: bad arguments");
   const long long blocks = (N + LN_COLS - 1) / LN_COLS;
   ADVHIP_REQUIRE(blocks < (1ll << 31), "head_ln_fc_bwd: too many positions");
-  hipLaunchKernelGGL(head_ln_fc_bwd_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, d_xn, d_score, y, ln_g, ln_b, fc_w, mean,
-                     rstd, score, dy, partial, C, (long long)N);
+  const bool v4 = C == 16 * LV_GROUPS && N % 4 == 0 &&
+                  (((uintptr_t)y | (uintptr_t)d_xn | (uintptr_t)d_score | (uintptr_t)mean | (uintptr_t)rstd | (uintptr_t)score | (uintptr_t)dy) & 15) == 0;
+  if (v4)
+    hipLaunchKernelGGL(head_ln_fc_bwd_v4_kernel<16>, dim3((unsigned)blocks), dim3(LV_THREADS), 0, (hipStream_t)stream, d_xn, d_score, y, ln_g, ln_b, fc_w,
+                       mean, rstd, score, dy, partial, (long long)N);
+  else
+    hipLaunchKernelGGL(head_ln_fc_bwd_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, d_xn, d_score, y, ln_g, ln_b, fc_w, mean,
+                       rstd, score, dy, partial, C, (long long)N);
   return check_launch("head_ln_fc_bwd");
 }
 
@@ -1302,7 +1846,7 @@ extern "C" int advhip_amp_combine_fwd_f32(const float* z, const float* bias, con
 extern "C" int advhip_amp_combine_bwd_f32(const float* dy, const float* mag, int64_t mag_stride, float ratio, float* dz, float* d_bias, float* d_wm,
                                           float* d_bm, int32_t O, int64_t rows, int32_t T, void* stream) {
   ADVHIP_REQUIRE(dy && mag && dz && d_bias && d_wm && d_bm && O > 0 && rows > 0 && T > 0 && mag_stride > 0, "amp_combine_bwd: bad arguments");
-  hipLaunchKernelGGL(amp_combine_bwd_kernel, dim3((unsigned)O), dim3(256), 0, (hipStream_t)stream, dy, mag, (long long)mag_stride, ratio, dz, d_bias, d_wm,
+  hipLaunchKernelGGL(amp_combine_bwd_kernel, dim3((unsigned)O), dim3(AMPB_THREADS), 0, (hipStream_t)stream, dy, mag, (long long)mag_stride, ratio, dz, d_bias, d_wm,
                      d_bm, O, (long long)rows, T);
   return check_launch("amp_combine_bwd");
 }
