@@ -293,6 +293,81 @@ __global__ __launch_bounds__(LV_THREADS) void chan_layernorm_bwd_v4_kernel(const
   }
 }
 
+// forward in the same blocking: y = (x - mu) * rs * g + b with the one-pass shifted statistics of ln_stats, x resident in registers
+template <int CPT>
+__global__ __launch_bounds__(LV_THREADS) void chan_layernorm_fwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                                           float* __restrict__ y, float* __restrict__ mu, float* __restrict__ rs, long long N,
+                                                                           float eps) {
+  constexpr int Cc = CPT * LV_GROUPS;
+  __shared__ float part[2][LV_THREADS / 64][LV_POS];
+  const int pl = threadIdx.x % LV_PL, grp = threadIdx.x / LV_PL, wave = threadIdx.x >> 6;
+  const long long n = blockIdx.x * (long long)LV_POS + 4 * pl;
+  const bool ok = n < N;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 v[CPT], x0 = zero4;
+#pragma unroll
+  for (int u = 0; u < CPT; ++u) v[u] = zero4;
+  if (ok) {
+    x0 = *reinterpret_cast<const float4*>(x + n);
+    const float* xp = x + (long long)grp * N + n;
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) v[u] = *reinterpret_cast<const float4*>(xp + (long long)u * LV_GROUPS * N);
+  }
+  float4 s1 = zero4, s2 = zero4;
+#pragma unroll
+  for (int u = 0; u < CPT; ++u) {
+    const float4 d = make_float4(v[u].x - x0.x, v[u].y - x0.y, v[u].z - x0.z, v[u].w - x0.w);
+    s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+    s2.x += d.x * d.x; s2.y += d.y * d.y; s2.z += d.z * d.z; s2.w += d.w * d.w;
+  }
+#pragma unroll
+  for (int off = LV_PL; off < 64; off <<= 1) {
+    s1.x += __shfl_xor(s1.x, off, 64); s1.y += __shfl_xor(s1.y, off, 64); s1.z += __shfl_xor(s1.z, off, 64); s1.w += __shfl_xor(s1.w, off, 64);
+    s2.x += __shfl_xor(s2.x, off, 64); s2.y += __shfl_xor(s2.y, off, 64); s2.z += __shfl_xor(s2.z, off, 64); s2.w += __shfl_xor(s2.w, off, 64);
+  }
+  if ((threadIdx.x & 63) < LV_PL) {
+    *reinterpret_cast<float4*>(&part[0][wave][4 * pl]) = s1;
+    *reinterpret_cast<float4*>(&part[1][wave][4 * pl]) = s2;
+  }
+  __syncthreads();
+  if (!ok) return;
+  float4 t1 = zero4, t2 = zero4;
+#pragma unroll
+  for (int w = 0; w < LV_THREADS / 64; ++w) {
+    const float4 a1 = *reinterpret_cast<const float4*>(&part[0][w][4 * pl]), a2 = *reinterpret_cast<const float4*>(&part[1][w][4 * pl]);
+    t1.x += a1.x; t1.y += a1.y; t1.z += a1.z; t1.w += a1.w;
+    t2.x += a2.x; t2.y += a2.y; t2.z += a2.z; t2.w += a2.w;
+  }
+  const float inv = 1.f / (float)Cc;
+  const float4 m1 = make_float4(t1.x * inv, t1.y * inv, t1.z * inv, t1.w * inv);
+  const float4 mean = make_float4(x0.x + m1.x, x0.y + m1.y, x0.z + m1.z, x0.w + m1.w);
+  const float4 r = make_float4(1.f / (sqrtf(fmaxf(t2.x * inv - m1.x * m1.x, 0.f)) + eps), 1.f / (sqrtf(fmaxf(t2.y * inv - m1.y * m1.y, 0.f)) + eps),
+                               1.f / (sqrtf(fmaxf(t2.z * inv - m1.z * m1.z, 0.f)) + eps), 1.f / (sqrtf(fmaxf(t2.w * inv - m1.w * m1.w, 0.f)) + eps));
+  if (grp == 0) {
+    *reinterpret_cast<float4*>(mu + n) = mean;
+    *reinterpret_cast<float4*>(rs + n) = r;
+  }
+  float* yp = y + (long long)grp * N + n;
+#pragma unroll
+  for (int u = 0; u < CPT; ++u) {
+    const int c = grp + u * LV_GROUPS;
+    const float gc = g[c], bc = b[c];
+    *reinterpret_cast<float4*>(yp + (long long)u * LV_GROUPS * N) =
+        make_float4((v[u].x - mean.x) * r.x * gc + bc, (v[u].y - mean.y) * r.y * gc + bc, (v[u].z - mean.z) * r.z * gc + bc, (v[u].w - mean.w) * r.w * gc + bc);
+  }
+}
+
+static bool launch_ln_fwd_v4(const float* x, const float* g, const float* b, float* y, float* mu, float* rs, int C, long long N, float eps, hipStream_t st) {
+  if (N % 4 != 0 || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)mu | (uintptr_t)rs) & 15) != 0) return false;
+  const dim3 grid((unsigned)((N + LV_POS - 1) / LV_POS)), block(LV_THREADS);
+  switch (C) {
+    case 1 * LV_GROUPS: hipLaunchKernelGGL(chan_layernorm_fwd_v4_kernel<1>, grid, block, 0, st, x, g, b, y, mu, rs, N, eps); return true;
+    case 2 * LV_GROUPS: hipLaunchKernelGGL(chan_layernorm_fwd_v4_kernel<2>, grid, block, 0, st, x, g, b, y, mu, rs, N, eps); return true;
+    case 16 * LV_GROUPS: hipLaunchKernelGGL(chan_layernorm_fwd_v4_kernel<16>, grid, block, 0, st, x, g, b, y, mu, rs, N, eps); return true;
+    default: return false;
+  }
+}
+
 static bool launch_ln_bwd_v4(const float* dy, const float* x, const float* g, const float* mu, const float* rs, float* dx, float* pg, float* pb, int C,
                              long long N, float eps, const float* add, long long prow, hipStream_t st) {
   static_assert(LV_POS == LN_COLS, "the partial-sum matrices have one row per LN_COLS positions (advhip_chan_layernorm_bwd_partial_rows)");
@@ -1541,8 +1616,9 @@ extern "C" int advhip_chan_layernorm_fwd_f32(const float* x, const float* g, con
   ADVHIP_REQUIRE(x && g && b && y && mu && rs && C > 0 && N > 0, "chan_layernorm_fwd: bad arguments");
   const long long blocks = (N + LN_COLS - 1) / LN_COLS;
   ADVHIP_REQUIRE(blocks < (1ll << 31), "chan_layernorm_fwd: too many positions");
-  hipLaunchKernelGGL(chan_layernorm_fwd_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, x, g, b, y, mu, rs, C,
-                     (long long)N, eps);
+  if (!launch_ln_fwd_v4(x, g, b, y, mu, rs, C, (long long)N, eps, (hipStream_t)stream))
+    hipLaunchKernelGGL(chan_layernorm_fwd_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, x, g, b, y, mu, rs, C,
+                       (long long)N, eps);
   return check_launch("chan_layernorm_fwd");
 }
 

@@ -509,6 +509,12 @@ def _defer_dw(g2: torch.Tensor, x2: torch.Tensor, wparam, bparam) -> bool:
 K3_AS_GEMM = os.environ.get("ADV_MGFN_K3_GEMM", "1") == "1"
 
 
+# the input gradient of a NARROW k = 3 layer (<= this many channels: stages 0 and 1) straight from the im2col-free transposed conv:
+# such a launch is bound by its latency chain, not by the gather's issue rate, so the unfold3(dY) pass in front of the GEMM form
+# is one launch (~5.5 us each, six per step) for nothing
+NARROW_DX_DIRECT = int(os.environ.get("ADV_MGFN_NARROW_DX_DIRECT", "128"))
+
+
 class _LinearCN(torch.autograd.Function):
     """y = conv1d_k(x; W) + b (+ residual), k in {1, 3}, no activation."""
 
@@ -544,7 +550,7 @@ class _LinearCN(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if k == 1:  # dX = W^T dY: the parameter's own (o, c) layout IS the kernels' [K = o][Cout = c] operand
                 dx = conv_cn(dy, weight.detach().view(cout, cin), cin, 1, residual=dy if fold else None)
-            elif ctx.unfolded:  # transposed conv as a GEMM over unfold3(dY): rows (o*3 + j') = dY[o, n + j' - 1] against pack_dx's
+            elif ctx.unfolded and min(cin, cout) > NARROW_DX_DIRECT:  # transposed conv as a GEMM over unfold3(dY): rows (o*3 + j') = dY[o, n + j' - 1] against pack_dx's
                 ud = _unfold3(dy).view(3 * cout, dy.shape[1], dy.shape[2])  # [(o*3 + j')][c] = W[o][c][2 - j']
                 wdx = ctx.dx_pack if ctx.dx_pack is not None else pack_dx(weight.detach())
                 dx = conv_cn(ud, wdx, cin, 1, residual=dy if fold else None)

@@ -284,10 +284,13 @@ class Trainer:
             for batch_idx, batch in enumerate(self._max_size_cycle(nloader, aloader)):
                 if 0 <= self.max_steps <= self.global_step:
                     break
-                batch = _to_device(batch, self.device)
-                if graphed is not None:
-                    runner.log("train_loss", graphed(*runner.training_batch(batch)))
+                if graphed is not None and self._feed_graph_inputs(graphed, batch):
+                    # (the host batch went straight into the captured step's input buffers: no torch.cat, no staging copy)
+                    runner.log("train_loss", graphed(*graphed.inputs()))
+                elif graphed is not None:
+                    runner.log("train_loss", graphed(*runner.training_batch(_to_device(batch, self.device))))
                 else:
+                    batch = _to_device(batch, self.device)
                     optimizer.zero_grad(set_to_none=True)
                     loss = runner.training_step(batch, batch_idx)
                     loss.backward()
@@ -311,6 +314,30 @@ class Trainer:
                     cb.on_epoch_end(self, runner, optimizer, epoch, epoch_metrics)
             if 0 <= self.max_steps <= self.global_step:
                 break
+
+    @staticmethod
+    def _feed_graph_inputs(graphed, batch) -> bool:
+        """Copy a (normal, abnormal) loader batch into the captured step's input buffers: normal features into rows [0, B) of the
+        video buffer, abnormal ones into [B, 2B) (src/runner.py:29-39's torch.cat order), the two label vectors into theirs.
+        False (nothing written) while there is no graph or when the batch has another shape."""
+        static = graphed.inputs()
+        if static is None:
+            return False
+        try:
+            ninputs, ainputs = batch
+            nf, af, al, nl = ninputs["feature"], ainputs["feature"], ainputs["anomaly"], ninputs["anomaly"]
+        except (TypeError, KeyError, ValueError):
+            return False
+        video, s_al, s_nl = static
+        b = nf.shape[0]
+        if (af.shape != nf.shape or (2 * b,) + tuple(nf.shape[1:]) != tuple(video.shape) or tuple(al.shape) != tuple(s_al.shape)
+                or tuple(nl.shape) != tuple(s_nl.shape)):
+            return False
+        video[:b].copy_(nf, non_blocking=True)
+        video[b:].copy_(af, non_blocking=True)
+        s_al.copy_(al, non_blocking=True)
+        s_nl.copy_(nl, non_blocking=True)
+        return True
 
     @torch.no_grad()
     def validate(self, runner: VideoAnomalyDetectionRunner) -> Dict[str, float]:

@@ -81,6 +81,12 @@ class GraphedTrainStep:
                         for g in self.optimizer.param_groups for p in g["params"] if p in state)
         return (groups, self.clip, tuple(p.data_ptr() for p in self.model.parameters()), moments)
 
+    def inputs(self) -> Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+        """The captured graph's own input buffers (video, abnormal_labels, normal_labels), or None while there is no graph.  A feeder
+        that writes the next batch straight into them -- runner.Trainer copies the host batch there -- and then calls
+        `step(*step.inputs())` saves the device-to-device staging copy of the batch (84 MB at the runner's batch shape)."""
+        return self.static if self.graph is not None else None
+
     def _finish(self) -> None:
         mgfn_ops.invalidate_caches()  # (fused / captured optimizers do not move version counters)
         if self.after_step is not None:
@@ -97,7 +103,8 @@ class GraphedTrainStep:
             self.eager_left = 1 << 62 if self.captures >= self.MAX_CAPTURES else 1
         if self.graph is not None and key == self._key:
             for dst, src in zip(self.static, (video, abnormal_labels, normal_labels)):
-                dst.copy_(src)
+                if src.data_ptr() != dst.data_ptr():  # (a caller that filled `inputs()` in place has nothing to copy)
+                    dst.copy_(src)
             self.graph.replay()
             self.replays += 1
             self._finish()
