@@ -174,7 +174,15 @@ __device__ __forceinline__ float act_gelu(float x) { return 0.5f * x * (1.f + er
 __device__ __forceinline__ float act_gelu_grad(float x) {
   return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * expf(-0.5f * x * x) * 0.39894228040143267794f;
 }
-__device__ __forceinline__ float act_apply(int code, float v) { return code == 1 ? fmaxf(v, 0.f) : (code == 2 ? act_gelu(v) : v); }
+// activation codes (advhip_conv3d_desc::relu): 0 none, 1 ReLU, 2 GELU, 3 GELU with GELU'(pre-activation) as the second output (instead of
+// the pre-activation itself), 4 none + the result multiplied by the `dact` tensor AS IS (a GELU' saved by a code-3 forward: the fused GELU
+// backward without an erf / exp in the backward epilogue)
+constexpr int ACT_GELU_D = 3, ACT_MUL = 4;
+__device__ __forceinline__ float act_apply(int code, float v) { return code == 1 ? fmaxf(v, 0.f) : ((code == 2 || code == ACT_GELU_D) ? act_gelu(v) : v); }
+// what the second output holds for pre-activation value v
+__device__ __forceinline__ float act_second(int code, float v) { return code == ACT_GELU_D ? act_gelu_grad(v) : v; }
+// the `dact` factor for a stored operand value
+__device__ __forceinline__ float act_dact(int code, float op) { return code == ACT_MUL ? op : act_gelu_grad(op); }
 
 // ---- the pipelined epilogue: y = act(acc * scale + shift (+ res)) (* GELU'(z)), act in {none, ReLU, GELU (+ the pre-activation as a
 // second output)} -- every conv of the I3D plan and every MGFN GEMM without a LayerNorm fold.  Same arithmetic, LDS transposition
@@ -193,17 +201,20 @@ __device__ __forceinline__ float act_apply(int code, float v) { return code == 1
 #ifndef SPLITK_SUM_BATCH
 #define SPLITK_SUM_BATCH 4
 #endif
-enum EpiMode { EM_PLAIN = 0, EM_RES = 1, EM_DACT = 2, EM_GELU = 3 };  // operand read per piece: none / residual / z of GELU'(z); act: ReLU flag / GELU
+// operand read per piece: none / residual / z of GELU'(z) / a multiplier; act: ReLU flag / GELU (second output: pre-activation) / GELU
+// (second output: GELU'(pre-activation))
+enum EpiMode { EM_PLAIN = 0, EM_RES = 1, EM_DACT = 2, EM_GELU = 3, EM_MUL = 4, EM_GELU2 = 5 };
 
 template <int BM, int BN, int BK, int MODE>
 __device__ __forceinline__ void igemm_epilogue_plain(const ConvArgs& a, f32x4 (&acc)[BM / 32][BN / 32], float* smem, int m0, int n0, int wave, int lane) {
   using Cfg = IgemmCfg<BM, BN, BK>;
   constexpr int FM = Cfg::FM, FN = Cfg::FN;
-  constexpr bool OPERAND = MODE == EM_RES || MODE == EM_DACT;
+  constexpr bool OPERAND = MODE == EM_RES || MODE == EM_DACT || MODE == EM_MUL;
+  constexpr bool SECOND = MODE == EM_GELU || MODE == EM_GELU2;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lg = lane >> 4;
   float* st = smem + wave * (16 * Cfg::ST_STRIDE);
-  const bool relu = a.relu != 0;
+  const bool relu = a.relu == 1;
   const float* __restrict__ opnd = MODE == EM_RES ? a.res : a.dact;
   // channel n0 + wn*WN + c of this wave's tile: lane c holds its scale / shift (WN = 32: the upper lanes repeat the lower ones)
   const int cn = n0 + wn * Cfg::WN + (lane & (Cfg::WN - 1));
@@ -231,9 +242,17 @@ __device__ __forceinline__ void igemm_epilogue_plain(const ConvArgs& a, f32x4 (&
     v = v * sc + sf;
     if constexpr (MODE == EM_RES) v += op;
     pre = v;
-    if constexpr (MODE == EM_GELU) v = act_gelu(v);
-    else v = relu ? fmaxf(v, 0.f) : v;
+    if constexpr (MODE == EM_GELU) {
+      v = act_gelu(v);
+    } else if constexpr (MODE == EM_GELU2) {  // y = GELU(v), second output = GELU'(v): one erf for both
+      const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752440f));
+      pre = cdf + v * expf(-0.5f * v * v) * 0.39894228040143267794f;
+      v = v * cdf;
+    } else if constexpr (MODE != EM_MUL) {
+      v = relu ? fmaxf(v, 0.f) : v;
+    }
     if constexpr (MODE == EM_DACT) v *= act_gelu_grad(op);
+    if constexpr (MODE == EM_MUL) v *= op;
     return v;
   };
   if (a.vw == 4) {
@@ -273,7 +292,7 @@ __device__ __forceinline__ void igemm_epilogue_plain(const ConvArgs& a, f32x4 (&
           if (k + W < NP) issue(k + W);
         }
         const size_t po = (size_t)((unsigned)(FN * RPI * i + jn) * thwo);
-        if constexpr (MODE == EM_GELU) {
+        if constexpr (SECOND) {
           if (a.y2 && mok) vec_store<4>(a.y2 + yoff + po, pre);
         }
         if (mok) vec_store<4>(yp0 + po, v);
@@ -319,7 +338,7 @@ __device__ __forceinline__ void igemm_epilogue_plain(const ConvArgs& a, f32x4 (&
           if (k + W < NP) issue(k + W);
         }
         const size_t po = (size_t)((unsigned)(FN * RPI * i + jn) * thwo);
-        if constexpr (MODE == EM_GELU) {
+        if constexpr (SECOND) {
           if (a.y2 && mok) a.y2[yoff + po] = pre;
         }
         if (mok) yp0[po] = v;
@@ -345,8 +364,11 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[B
     // their erf temporaries spill, and scratch in a kernel costs the whole plan more than these forms gain on small layers.
     if constexpr (BM * BN >= 128 * 128) {
       if (a.relu == 2 && !a.res && !a.dact) { igemm_epilogue_plain<BM, BN, BK, EM_GELU>(a, acc, smem, m0, n0, wave, lane); return; }
+      if (a.relu == ACT_GELU_D && !a.res && !a.dact) { igemm_epilogue_plain<BM, BN, BK, EM_GELU2>(a, acc, smem, m0, n0, wave, lane); return; }
       if (a.relu <= 1 && !a.y2 && a.dact && !a.res) { igemm_epilogue_plain<BM, BN, BK, EM_DACT>(a, acc, smem, m0, n0, wave, lane); return; }
     }
+    // (the multiplier form has no transcendental in it: every tile takes the pipelined epilogue)
+    if (a.relu == ACT_MUL && a.dact && !a.res && !a.y2) { igemm_epilogue_plain<BM, BN, BK, EM_MUL>(a, acc, smem, m0, n0, wave, lane); return; }
     if (a.relu <= 1 && !a.y2 && !a.dact) {
       if (a.res) igemm_epilogue_plain<BM, BN, BK, EM_RES>(a, acc, smem, m0, n0, wave, lane);
       else igemm_epilogue_plain<BM, BN, BK, EM_PLAIN>(a, acc, smem, m0, n0, wave, lane);
@@ -408,7 +430,12 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[B
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] += rv[e];
             }
-            if (a.y2) vec_store<4>(a.y2 + oy, v);
+            if (a.y2) {
+              float sv[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) sv[e] = act_second(a.relu, v[e]);
+              vec_store<4>(a.y2 + oy, sv);
+            }
             if (a.relu) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = act_apply(a.relu, v[e]);
@@ -417,7 +444,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[B
               float zv[4];
               vec_load<4>(a.dact + o, zv);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] *= act_gelu_grad(zv[e]);
+              for (int e = 0; e < 4; ++e) v[e] *= act_dact(a.relu, zv[e]);
             }
           }
           vec_store<4>(yout + oy, v);
@@ -471,9 +498,9 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[B
             if (a.ln_u) v = v * a.ln_rs[mm] - a.ln_u[n] * (a.ln_mu[mm] * a.ln_rs[mm]);
             v = v * a.scale[n] + a.shift[n];
             if (a.res) v += a.res[o];
-            if (a.y2) a.y2[oy] = v;
+            if (a.y2) a.y2[oy] = act_second(a.relu, v);
             if (a.relu) v = act_apply(a.relu, v);
-            if (a.dact) v *= act_gelu_grad(a.dact[o]);
+            if (a.dact) v *= act_dact(a.relu, a.dact[o]);
           }
           yout[oy] = v;
         }
@@ -1878,7 +1905,12 @@ void conv1x1_persist_kernel(const ConvArgs a, const int n_xcd) {
       float x4[4] = {vv[0], vv[1], vv[2], vv[3]};
       if (vec) {
         if (a.res) { x4[0] += rv[i][0]; x4[1] += rv[i][1]; x4[2] += rv[i][2]; x4[3] += rv[i][3]; }
-        if (a.y2) vec_store<4>(a.y2 + oy, x4);
+        if (a.y2) {
+          float sv[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) sv[c] = act_second(a.relu, x4[c]);
+          vec_store<4>(a.y2 + oy, sv);
+        }
         if (a.relu) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) x4[c] = act_apply(a.relu, x4[c]);
@@ -1892,7 +1924,7 @@ void conv1x1_persist_kernel(const ConvArgs a, const int n_xcd) {
           if (epp + c < a.THWo) {
             float val = x4[c];
             if (a.res) val += a.res[o + c];
-            if (a.y2) a.y2[oy + c] = val;
+            if (a.y2) a.y2[oy + c] = act_second(a.relu, val);
             if (a.relu) val = act_apply(a.relu, val);
             a.y[oy + c] = val;
           }
@@ -3035,7 +3067,9 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
   float* avg_out = ep ? ep->avgpool_out : nullptr;
   const bool ln = ep && ep->ln_u;
   ADVHIP_REQUIRE(!ep || (!ep->ln_u == !ep->ln_mu && !ep->ln_u == !ep->ln_rs), "conv3d: the LayerNorm fold needs ln_u, ln_mu and ln_rs together");
-  ADVHIP_REQUIRE(d->relu >= 0 && d->relu <= 2, "conv3d: unknown activation code %d (0 none, 1 ReLU, 2 GELU)", d->relu);
+  ADVHIP_REQUIRE(d->relu >= 0 && d->relu <= ACT_MUL, "conv3d: unknown activation code %d (0 none, 1 ReLU, 2 GELU, 3 GELU + GELU' output, 4 multiplier)", d->relu);
+  ADVHIP_REQUIRE(d->relu != ACT_GELU_D || (ep && ep->y_preact), "conv3d: activation code 3 writes GELU'(pre-activation) to the epilogue's second output: y_preact is null");
+  ADVHIP_REQUIRE(d->relu != ACT_MUL || (ep && ep->dact_z && residual == nullptr), "conv3d: activation code 4 multiplies by the epilogue's dact_z tensor (no residual): it is null");
   ADVHIP_REQUIRE(x && w_packed && ktab && scale && shift && (y || avg_out), "conv3d: null pointer");
   const Geometry g = geometry(d);
   ConvArgs a;

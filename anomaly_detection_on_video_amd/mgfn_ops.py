@@ -32,6 +32,10 @@ from . import _lib, ops
 from ._lib import ConvDesc, ConvEpilogue, check, ptr, stream
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+# GELU whose second output is GELU'(pre-activation) instead of the pre-activation, and its consumer: the result times that tensor as is
+# (include/advhip.h, advhip_conv3d_desc::relu codes 3 / 4): the fused GELU backward then has no erf / exp in its epilogue and runs on
+# every tile's pipelined epilogue (the erf form: the 128 x 128 tile only)
+ACT_GELU_D, ACT_MUL = 3, 4
 ALGO = _lib.ALGO_DMA2_BASE + _lib.ALGO_IGEMM_128x64  # 128 x 64 x 16 tiles, 2-deep LDS-DMA ring: 139-146 TFLOP/s on these GEMMs
 
 _KTABS: Dict[Tuple, torch.Tensor] = {}
@@ -91,7 +95,10 @@ def _desc(cin: int, cout: int, k: int, b: int, t: int, act: int) -> ConvDesc:
         algo = ALGO_SMALL
         tiles = -(-n // 64) * (cout // 64)
         ktiles = -(-(cin * k) // 16)
-        while tiles * splits < 768 and splits < 8 and ktiles // (splits + 1) >= 16:
+        # (a very long K over a handful of tiles -- the token conv's weight gradient: K = all 10 240 positions, 99 tiles -- keeps gaining up
+        # to ~4.5 workgroups per CU: 12 slices 76 us, 8 slices 87, tools/time_token_gemms.py)
+        target, cap = (1152, 12) if ktiles >= 512 else (768, 8)
+        while tiles * splits < target and splits < cap and ktiles // (splits + 1) >= 16:
             splits += 1
     return ConvDesc(1, cin, 1, b, t, cout, 1, 1, k, 1, 1, 1, 0, 0, k // 2, act, algo, splits)
 
@@ -264,6 +271,8 @@ def conv_cn(x: torch.Tensor, w_packed: torch.Tensor, cout: int, k: int = 1, shif
     _lib.require_gpu(x, w_packed, shift, residual, dact_z, *(ln or ()), contiguous=False)
     if not x.is_contiguous():
         raise _lib.HipExtensionError("conv_cn needs a contiguous (C, B, T) activation")
+    if act == ACT_MUL and dact_z is None:
+        raise ValueError("conv_cn: ACT_MUL multiplies by the tensor passed as dact_z")
     if act != ACT_NONE and residual is not None:  # (the conv epilogue adds the residual BEFORE the activation, advhip_bgemm_f32 after)
         raise ValueError("conv_cn: an activation together with a residual is not offered (the two GEMM entry points order them differently)")
     d = _desc(cin, cout, k, 1 if k == 1 else b, b * t if k == 1 else t, act)
@@ -585,7 +594,8 @@ class _FFNCN(torch.autograd.Function):
     def forward(ctx, xh, x_res, w1, b1, w2, b2, fresh):
         hid, dim = w1.shape[0], w1.shape[1]
         need_z = any(ctx.needs_input_grad)
-        out = conv_cn(xh, pack_kc_cached(w1, fresh), hid, 1, shift=b1.detach(), act=ACT_GELU, want_preact=need_z)
+        # (with a backward pass to come: z holds GELU'(pre-activation), what that pass multiplies by)
+        out = conv_cn(xh, pack_kc_cached(w1, fresh), hid, 1, shift=b1.detach(), act=ACT_GELU_D if need_z else ACT_GELU, want_preact=need_z)
         h, z = out if need_z else (out, None)
         y = conv_cn(h, pack_kc_cached(w2, fresh), dim, 1, shift=b2.detach(), residual=x_res.detach().contiguous())
         if need_z:
@@ -602,7 +612,7 @@ class _FFNCN(torch.autograd.Function):
         with _Fork(dy, h) as fk:
             dw2, db2 = _dw_db(dy, h, ctx.needs_input_grad[4], ctx.needs_input_grad[5], w2p, b2p)
             fk.out(dw2, db2)
-        dz = conv_cn(dy, w2.detach().view(dim, hid), hid, 1, dact_z=z)          # (W2^T dY) * GELU'(z)
+        dz = conv_cn(dy, w2.detach().view(dim, hid), hid, 1, dact_z=z, act=ACT_MUL)  # (W2^T dY) * GELU'(pre-activation), saved by the forward
         with _Fork(dz, xh) as fk:
             dw1, db1 = _dw_db(dz, xh.detach(), ctx.needs_input_grad[2], ctx.needs_input_grad[3], w1p, b1p)
             fk.out(dw1, db1)
@@ -640,7 +650,7 @@ class _FFNBlockCN(torch.autograd.Function):
         gf, bf = g.detach().reshape(c).contiguous(), b.detach().reshape(c).contiguous()
         check(_lib.load().advhip_chan_layernorm_fwd_f32(ptr(x), ptr(gf), ptr(bf), ptr(xh), ptr(mu), ptr(rs), c, n, C.c_float(eps), stream(x)),
               "chan_layernorm_fwd")
-        h, z = conv_cn(xh, pack_kc_cached(w1, fresh), hid, 1, shift=b1.detach(), act=ACT_GELU, want_preact=True)
+        h, z = conv_cn(xh, pack_kc_cached(w1, fresh), hid, 1, shift=b1.detach(), act=ACT_GELU_D, want_preact=True)  # z = GELU'(pre-activation)
         y = conv_cn(h, pack_kc_cached(w2, fresh), c, 1, shift=b2.detach(), residual=x)
         ctx.save_for_backward(x, gf, mu, rs, xh, z, h, w1, w2)
         ctx.params = (w1, b1, w2, b2)
@@ -657,7 +667,7 @@ class _FFNBlockCN(torch.autograd.Function):
         dy = dy.contiguous()
         w1p, b1p, w2p, b2p = ctx.params
         dw2, db2 = _dw_db(dy, h, need[6], need[7], w2p, b2p)
-        dz = conv_cn(dy, w2.detach().view(dim, hid), hid, 1, dact_z=z)          # (W2^T dY) * GELU'(z)
+        dz = conv_cn(dy, w2.detach().view(dim, hid), hid, 1, dact_z=z, act=ACT_MUL)  # (W2^T dY) * GELU'(pre-activation), saved by the forward
         dw1, db1 = _dw_db(dz, xh, need[4], need[5], w1p, b1p)
         dxh = conv_cn(dz, w1.detach().view(hid, dim), dim, 1)
         lib = _lib.load()
@@ -797,6 +807,88 @@ class _GlanceAttnCore(torch.autograd.Function):
             check(lib.advhip_glance_attention_bwd_anyt_f32(ptr(dout.contiguous()), ptr(qkv), ptr(out), ptr(lse), ptr(dqkv), heads, b, t, dim_head,
                                                            C.c_float(scale), stream(qkv)), "glance_attention_bwd_anyt")
         return dqkv, None, None, None
+
+
+class _GlanceAttnBlockCN(torch.autograd.Function):
+    """y = x + to_out(core(to_qkv(LN(x)))): a whole `x = attention(x) + x` step of a GlanceBlock (modeling_mgfn.py:107-123, 145) as one
+    autograd node -- LayerNorm, GEMM, the attention core, GEMM + bias + residual -- whose LayerNorm-backward launch also adds the skip
+    connection's gradient (autograd's own add over the activation, one launch per block, is gone) and queues dg / db with the other
+    deferred column sums."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, eps, wqkv, wout, bout, heads, dim_head, scale, fresh):
+        _lib.require_gpu(x, g, b, wqkv, wout, bout, contiguous=False)
+        c = x.shape[0]
+        n = x.numel() // c
+        lib = _lib.load()
+        xh = torch.empty_like(x)
+        mu = torch.empty((n,), device=x.device, dtype=torch.float32)
+        rs = torch.empty_like(mu)
+        gf, bf = g.detach().reshape(c).contiguous(), b.detach().reshape(c).contiguous()
+        check(lib.advhip_chan_layernorm_fwd_f32(ptr(x), ptr(gf), ptr(bf), ptr(xh), ptr(mu), ptr(rs), c, n, C.c_float(eps), stream(x)), "chan_layernorm_fwd")
+        inner = heads * dim_head
+        qkv = conv_cn(xh, pack_kc_cached(wqkv, fresh), 3 * inner, 1)
+        _c3, bsz, t = qkv.shape
+        core = torch.empty((inner, bsz, t), device=x.device, dtype=torch.float32)
+        if t == 32:
+            p = torch.empty((bsz, heads, t, t), device=x.device, dtype=torch.float32)
+            check(lib.advhip_glance_attention_fwd_f32(ptr(qkv), ptr(core), ptr(p), heads, bsz, t, dim_head, C.c_float(scale), stream(x)), "glance_attention_fwd")
+            aux = (p,)
+        else:
+            lse = torch.empty((bsz, heads, t), device=x.device, dtype=torch.float32)
+            check(lib.advhip_glance_attention_fwd_anyt_f32(ptr(qkv), ptr(core), ptr(lse), heads, bsz, t, dim_head, C.c_float(scale), stream(x)),
+                  "glance_attention_fwd_anyt")
+            aux = (core, lse)
+        y = conv_cn(core, pack_kc_cached(wout, fresh), c, 1, shift=bout.detach(), residual=x)
+        ctx.save_for_backward(x, gf, mu, rs, xh, qkv, core, wqkv, wout, *aux)
+        ctx.params = (wqkv, wout, bout)
+        ctx.ln_params = (g, b)
+        ctx.args = (eps, heads, dim_head, scale, g.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gf, mu, rs, xh, qkv, core, wqkv, wout = ctx.saved_tensors[:9]
+        aux = ctx.saved_tensors[9:]
+        eps, heads, dim_head, scale, gshape = ctx.args
+        c = x.shape[0]
+        n = x.numel() // c
+        inner = heads * dim_head
+        _c3, bsz, t = qkv.shape
+        need = ctx.needs_input_grad
+        lib = _lib.load()
+        dy = dy.contiguous()
+        wqkvp, woutp, boutp = ctx.params
+        dwo, dbo = _dw_db(dy, core, need[5], need[6], woutp, boutp)
+        dcore = conv_cn(dy, wout.detach().view(c, inner), inner, 1)
+        dqkv = torch.empty_like(qkv)
+        if t == 32:
+            check(lib.advhip_glance_attention_bwd_f32(ptr(dcore), ptr(qkv), ptr(aux[0]), ptr(dqkv), heads, bsz, t, dim_head, C.c_float(scale), stream(x)),
+                  "glance_attention_bwd")
+        else:
+            check(lib.advhip_glance_attention_bwd_anyt_f32(ptr(dcore), ptr(qkv), ptr(aux[0]), ptr(aux[1]), ptr(dqkv), heads, bsz, t, dim_head, C.c_float(scale),
+                                                           stream(x)), "glance_attention_bwd_anyt")
+        dwq, _ = _dw_db(dqkv, xh, need[4], False, wqkvp, None)
+        dxh = conv_cn(dqkv, wqkv.detach().view(3 * inner, c), c, 1)
+        rows = lib.advhip_chan_layernorm_bwd_partial_rows(n)
+        dx = torch.empty_like(x)
+        pgb = torch.empty((rows, 2 * c), device=x.device, dtype=torch.float32)
+        check(lib.advhip_chan_layernorm_bwd_add_f32(ptr(dxh), ptr(x), ptr(gf), ptr(mu), ptr(rs), ptr(dy), ptr(dx), ptr(pgb), c, n, C.c_float(eps), stream(x)),
+              "chan_layernorm_bwd_add")
+        gp, bp = ctx.ln_params
+        if need[1] and need[2] and _defer_colsum(pgb, [(gp, 0, c), (bp, c, 2 * c)]):
+            return dx, None, None, None, dwq, dwo, dbo, None, None, None, None
+        sums = colsum(pgb)
+        return dx, sums[:c].reshape(gshape), sums[c:].reshape(gshape), None, dwq, dwo, dbo, None, None, None, None
+
+
+GLANCE_BLOCK = os.environ.get("ADV_MGFN_GLANCE_BLOCK", "1") == "1"  # (0: LayerNorm, the two GEMMs and the core as separate autograd nodes)
+
+
+def glance_attention_block_cn(x: torch.Tensor, norm, to_qkv, to_out, heads: int, dim_head: int, scale: float) -> torch.Tensor:
+    """x + to_out(attention(to_qkv(LN(x)))) with autograd, as one Function."""
+    fresh = _will_train(to_qkv.weight, to_out.weight, to_out.bias)
+    return _GlanceAttnBlockCN.apply(x.contiguous(), norm.g, norm.b, norm.eps, to_qkv.weight, to_out.weight, to_out.bias, heads, dim_head, scale, fresh)
 
 
 def glance_attention_ok(qkv: torch.Tensor, heads: int, dim_head: int) -> bool:

@@ -228,6 +228,11 @@ class GlanceAttention(nn.Module):
 
     def forward(self, x, residual: Optional[torch.Tensor] = None):  # (C, B, T)
         _, b, n = x.shape
+        if (mgfn_ops.GLANCE_BLOCK and residual is x and torch.is_grad_enabled() and mgfn_ops.fused_ok(x) and _hip(self.to_qkv, x) and _hip(self.to_out, x)
+                and self.to_qkv.bias is None and self.to_out.bias is not None and self.dim_head == 64
+                and self.to_qkv.weight.shape[0] == 3 * self.heads * self.dim_head):
+            # LN + to_qkv + attention core + to_out + skip as one autograd node (mgfn_ops._GlanceAttnBlockCN)
+            return mgfn_ops.glance_attention_block_cn(x, self.norm, self.to_qkv, self.to_out, self.heads, self.dim_head, self.scale)
         qkv = _pointwise(self.to_qkv, self.norm(x))
         if mgfn_ops.glance_attention_ok(qkv, self.heads, self.dim_head):  # scale, sim, softmax, v attn^T, layout: one HIP launch
             return _pointwise(self.to_out, mgfn_ops.glance_attention_core(qkv, self.heads, self.dim_head, self.scale), residual)
@@ -445,8 +450,10 @@ class MGFNForVideoAnomalyDetection(MGFNPreTrainedModel):
         elif self.training:
             # same call order as the reference: abnormal first, then normal (modeling_mgfn.py:364-372)
             h = batch_size // 2 if split else batch_size
-            keep_a = self.dropout(torch.ones((h, mag.shape[1]), device=mag.device, dtype=mag.dtype))
-            keep_n = self.dropout(torch.ones((h, mag.shape[1]), device=mag.device, dtype=mag.dtype))
+            # (ONE dropout call for both masks, rows [0, h) the abnormal call's and [h, 2h) the normal one's: the draws of the reference's
+            # two calls in its order, two launches instead of four)
+            keep = self.dropout(torch.ones((2 * h, mag.shape[1]), device=mag.device, dtype=mag.dtype))
+            keep_a, keep_n = keep[:h], keep[h:]
         else:
             keep_a = keep_n = None
         if split and batch_size % 2 == 0:

@@ -74,7 +74,10 @@ typedef struct advhip_conv3d_desc {
   int32_t Cout, kt, kh, kw;   /* weight (Cout, Cin, kt, kh, kw), bias-free */
   int32_t st, sh, sw;         /* stride */
   int32_t pt, ph, pw;         /* zero padding */
-  int32_t relu;               /* activation applied last: 0 none, 1 ReLU max(0,.), 2 GELU (erf form, nn.GELU()) */
+  int32_t relu;               /* activation applied last: 0 none, 1 ReLU max(0,.), 2 GELU (erf form, nn.GELU());
+                               * advhip_conv3d_bn_act_ex_f32 only: 3 = GELU, with GELU'(pre-activation) -- not the pre-activation -- written to
+                               * the epilogue's y_preact (what the backward pass multiplies by); 4 = no activation, the result multiplied by the
+                               * epilogue's dact_z tensor AS IS (a tensor saved by a code-3 forward: the GELU backward without erf / exp) */
   int32_t algo;               /* ADVHIP_ALGO_* */
   int32_t splits;             /* split-K factor: 0 = heuristic, 1 = none, n = n K-slices + reduce pass */
 } advhip_conv3d_desc;

@@ -416,6 +416,38 @@ def test_glance_attention_anyt_handles_a_peaked_softmax():
     assert torch.isfinite(out).all() and rel_err(out.cpu(), ref) < 1e-5
 
 
+@pytest.mark.parametrize("cin,cout,b,t", [(64, 1024, 768, 32), (64, 64, 20, 32), (128, 512, 10, 57), (64, 128, 320, 32)])
+def test_gelu_epilogue_codes_forward_pair_and_multiplier_backward(cin, cout, b, t):
+    """The GEMM epilogue's GELU forms (include/advhip.h, advhip_conv3d_desc::relu): code 2 = (GELU(z), z), code 3 = (GELU(z), GELU'(z)) --
+    what the FFN forward keeps for its backward pass --, and code 4 = the result times a tensor as is (the fused GELU backward without
+    erf / exp); on the 128 x 128 tile (the pipelined erf forms) and on the small tiles.  Against torch in fp64; the code-3 / code-4
+    pair must equal the code-2 / GELU'(z)-operand pair it replaces (modeling_mgfn.py:53-64's GELU and its derivative)."""
+    from anomaly_detection_on_video_amd import mgfn_ops
+
+    x = synth_tensor(f"ge.x{cin}{cout}", (cin, b, t), scale=1.0).to(DEV)
+    w = synth_tensor(f"ge.w{cin}{cout}", (cout, cin, 1), scale=cin ** -0.5).to(DEV)
+    bias = synth_tensor(f"ge.b{cout}", (cout,), scale=0.3).to(DEV)
+    wp = mgfn_ops.pack_kc(w)
+    h2, z = mgfn_ops.conv_cn(x, wp, cout, 1, shift=bias, act=mgfn_ops.ACT_GELU, want_preact=True)
+    h3, dz = mgfn_ops.conv_cn(x, wp, cout, 1, shift=bias, act=mgfn_ops.ACT_GELU_D, want_preact=True)
+    zr = torch.einsum("oc,cbt->obt", w[:, :, 0].double().cpu(), x.double().cpu()) + bias.double().cpu()[:, None, None]
+    zr.requires_grad_(True)
+    hr = torch.nn.functional.gelu(zr)
+    (gr,) = torch.autograd.grad(hr.sum(), zr)
+    assert rel_err(z.cpu(), zr.detach()) < 1e-5 and rel_err(h2.cpu(), hr.detach()) < 1e-5
+    assert rel_err(h3.cpu(), hr.detach()) < 1e-5 and rel_err(dz.cpu(), gr) < 1e-5
+    # backward GEMM: (W^T dY) * GELU'(z), from z (code 0 + dact_z) and from the stored derivative (code 4)
+    dy = synth_tensor(f"ge.dy{cin}{cout}", (cin, b, t), scale=1.0).to(DEV)
+    wt = synth_tensor(f"ge.wt{cin}{cout}", (cout, cin, 1), scale=cin ** -0.5).to(DEV)  # (any (cout, cin) operand: the product is what is checked)
+    wtp = mgfn_ops.pack_kc(wt)
+    via_z = mgfn_ops.conv_cn(dy, wtp, cout, 1, dact_z=z)
+    via_d = mgfn_ops.conv_cn(dy, wtp, cout, 1, dact_z=dz, act=mgfn_ops.ACT_MUL)
+    ref = torch.einsum("oc,cbt->obt", wt[:, :, 0].double().cpu(), dy.double().cpu()) * gr
+    assert rel_err(via_z.cpu(), ref) < 1e-5 and rel_err(via_d.cpu(), ref) < 1e-5
+    with pytest.raises(Exception):
+        mgfn_ops.conv_cn(dy, wtp, cout, 1, act=mgfn_ops.ACT_MUL)  # the multiplier is missing
+
+
 @pytest.mark.parametrize("c,b,t", [(1024, 320, 32), (1024, 10, 57), (96, 3, 5), (200, 2, 33)])
 def test_head_layernorm_linear_sigmoid_fwd_bwd_vs_fp64_autograd(c, b, t):
     """advhip_head_ln_fc_fwd/bwd_f32 -- nn.LayerNorm(C) + nn.Linear(C, 1) + sigmoid on the body's (C, B, T) layout, xn written
