@@ -257,6 +257,9 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the default PCIe-inclusive legs")
     ap.add_argument("--sustain-s", type=float, default=3.0, help="seconds of back-to-back steps after the K timed ones (the `sustained` record: DVFS shows here)")
     ap.add_argument("--no-mgfn-train", action="store_true", help="skip the MGFN training-step record (config 4)")
+    ap.add_argument("--stream-start", type=int, default=-1, help="crop-clip position the synthetic stream is picked up at (default: such that a video ends "
+                    "in the middle of the timed steps); 0 in the PMC passes of tools/profile_bench.sh: no video completes in their few steps, so the "
+                    "conv-kernel counters are the backbone's alone (the scorer's GEMMs run on the same kernels)")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous only (gloo, no GPU): checks the rank launch + result relay")
     args = ap.parse_args()
 
@@ -306,7 +309,7 @@ def main():
     # the synthetic UCF-Crime-shaped stream (SURVEY 8(d) cfg 3): n_clips ~ U[50, 500] per video, 10 crops per clip; every video is
     # scored with T = its own clip count when its last crop-clip has arrived
     stream = ExtractScoreStream(backbone, scorer, clips_per_video=clips, ncrops=10, local_batch=args.batch, world=world, rank=rank)
-    pos0 = stream_start(clips, 10, args.batch * world, args.warmup, args.steps)
+    pos0 = stream_start(clips, 10, args.batch * world, args.warmup, args.steps) if args.stream_start < 0 else args.stream_start
     stream.seek(pos0)
     stream.ring.uniform_(0.0, 3.0)  # (the rows of the picked-up video that lie before the stream's start: plausible features, not zeros)
 

@@ -22,11 +22,11 @@ if ROOT not in sys.path:
 # "small": W videos of 3 clips x 2 crops in 3 global batches of 2W crop-clips of 16 x 48 x 48 (ordering / ownership logic);
 # "bench": the benchmarked shape -- 32 crop-clips of 16 x 224 x 224 per rank and step (the tuned B = 32 plan, its split-K
 # launches on per-stream counter blocks, the stream's lanes), 2 steps, videos of 4 clips x 10 crops so that some complete
-# "ragged": BASELINE config 3's variable-length stream in miniature -- videos of 5, 2, 7, 3 clips x 2 crops (cyclic), global batches that end one
+# "ragged": BASELINE config 3's variable-length stream in miniature -- videos of 5, 3, 7, 4 clips x 2 crops (never fewer than k = 3: torch.topk raises in the reference too) (cyclic), global batches that end one
 # video and begin the next, every video scored with T = its own clip count by rank v % W
 CONFIGS = {
     "small": dict(clips_per_video=3, ncrops=2, local_batch=2, steps=3, hw=48),
-    "ragged": dict(clips_per_video=[5, 2, 7, 3], ncrops=2, local_batch=2, steps=9, hw=48),
+    "ragged": dict(clips_per_video=[5, 3, 7, 4], ncrops=2, local_batch=2, steps=9, hw=48),
     "bench": dict(clips_per_video=4, ncrops=10, local_batch=32, steps=2, hw=224),
 }
 CLIPS_PER_VIDEO, NCROPS, LOCAL_BATCH, STEPS = 3, 2, 2, 3  # (the "small" configuration, by its old names)
