@@ -3011,20 +3011,26 @@ static void set_bricks(ConvArgs& a, int nbt, int nbh, int nbw);  // defined with
 
 // the 2-deep-ring LDS-DMA kernel of a tile: unchecked (1x1x1, no padding), 16-byte gather pieces ((kt,1,1) stride-1 convs on
 // planes of a multiple of 4 positions, 16-deep k-tiles), or the 4-byte gather
+// ADVHIP_EXTRA_LDS (study builds only, default 0): unused dynamic LDS per workgroup of the 2-deep-ring kernels -- fewer workgroups of
+// one launch per CU, so that launches of different lanes share a CU (profiles/r05_studies.md section 5)
+#ifndef ADVHIP_EXTRA_LDS
+#define ADVHIP_EXTRA_LDS 0
+#endif
 template <int BM_, int BN_, int BK_>
 static void launch_dma2(bool nocheck, bool s16, dim3 grid, hipStream_t st, const ConvArgs& a) {
+  constexpr unsigned XL = ADVHIP_EXTRA_LDS;
   if (nocheck) {
-    if (a.a16) hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, false, 2, EPI_STD, false, 2>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, false, 2>), grid, dim3(256), 0, st, a);
+    if (a.a16) hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, false, 2, EPI_STD, false, 2>), grid, dim3(256), XL, st, a);
+    else hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, false, 2>), grid, dim3(256), XL, st, a);
     return;
   }
   if constexpr (BK_ == 16) {
     if (s16) {
-      hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, true, 2, EPI_STD, false, 1>), grid, dim3(256), 0, st, a);
+      hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, true, 2, EPI_STD, false, 1>), grid, dim3(256), XL, st, a);
       return;
     }
   }
-  hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, true, 2>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL((conv3d_igemm_dma_kernel<BM_, BN_, BK_, true, 2>), grid, dim3(256), XL, st, a);
 }
 
 }
