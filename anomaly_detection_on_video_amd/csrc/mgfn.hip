@@ -1269,28 +1269,40 @@ __device__ __forceinline__ void ga_load_tile(float (*dst)[GA_T + 1], const float
   }
 }
 
+// (LDS images with 16-byte aligned rows, pitch GA_P: the inner loops read k and the transposed softmax tile as float4 -- a third
+// of the LDS instructions of the one-dword form, which is what a workgroup's ~10 sequential key tiles at T = 290 spend their time on)
+constexpr int GA_P = GA_T + 4;
+__device__ __forceinline__ void ga_load_tile_p(float (*dst)[GA_P], const float* __restrict__ src, long long row0, long long N, long long col0,
+                                               int t_base, int T, int tid) {
+  for (int e = tid; e < GA_D * GA_T; e += 256) {
+    const int d = e / GA_T, t = e % GA_T, tt = t_base + t;
+    dst[d][t] = tt < T ? src[(row0 + d) * N + col0 + tt] : 0.f;
+  }
+}
+
 __global__ __launch_bounds__(256) void glance_attn_fwd_anyt_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ lse,
                                                                    int inner, int heads, int T, long long N, float scale, int bh0) {
-  __shared__ float q[GA_D][GA_T + 1], k[GA_D][GA_T + 1], v[GA_D][GA_T + 1], p[GA_T][GA_T + 1], alpha_s[GA_T], l_s[GA_T];
+  __shared__ __attribute__((aligned(16))) float q[GA_D][GA_P], k[GA_D][GA_P], v[GA_D][GA_P], pT[GA_T][GA_P];  // pT[j][i] = p[i][j]
+  __shared__ float alpha_s[GA_T], l_s[GA_T];
   const int bh = bh0 + blockIdx.y, b = bh / heads, h = bh % heads, tid = threadIdx.x;
   const int i_base = blockIdx.x * GA_T;
   const long long col0 = (long long)b * T, row0 = (long long)h * GA_D;
-  ga_load_tile(q, qkv, row0, N, col0, i_base, T, tid);
+  ga_load_tile_p(q, qkv, row0, N, col0, i_base, T, tid);
   const int i = tid >> 3, j0 = (tid & 7) * 4;   // sim: row i, columns j0 .. j0 + 3
   const int d2 = tid >> 2, i0 = (tid & 3) * 8;  // out: channel d2, queries i0 .. i0 + 7
   float m = GA_NEG, l = 0.f, o[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = 0.f;
   for (int jb = 0; jb < T; jb += GA_T) {
-    __syncthreads();  // (the previous tile's readers of k, v, p, alpha_s are done; first pass: q is complete)
-    ga_load_tile(k, qkv, inner + row0, N, col0, jb, T, tid);
-    ga_load_tile(v, qkv, 2ll * inner + row0, N, col0, jb, T, tid);
+    __syncthreads();  // (the previous tile's readers of k, v, pT, alpha_s are done; first pass: q is complete)
+    ga_load_tile_p(k, qkv, inner + row0, N, col0, jb, T, tid);
+    ga_load_tile_p(v, qkv, 2ll * inner + row0, N, col0, jb, T, tid);
     __syncthreads();
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     for (int d = 0; d < GA_D; ++d) {
       const float qi = q[d][i];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) s[e] += qi * k[d][j0 + e];
+      const float4 kv = *reinterpret_cast<const float4*>(&k[d][j0]);
+      s[0] += qi * kv.x; s[1] += qi * kv.y; s[2] += qi * kv.z; s[3] += qi * kv.w;
     }
     float mx = GA_NEG;
 #pragma unroll
@@ -1307,7 +1319,7 @@ __global__ __launch_bounds__(256) void glance_attn_fwd_anyt_kernel(const float* 
     for (int e = 0; e < 4; ++e) {
       s[e] = (jb + j0 + e < T) ? expf(s[e] - m_new) : 0.f;
       sum += s[e];
-      p[i][j0 + e] = s[e];
+      pT[j0 + e][i] = s[e];
     }
 #pragma unroll
     for (int off = 4; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
@@ -1315,13 +1327,13 @@ __global__ __launch_bounds__(256) void glance_attn_fwd_anyt_kernel(const float* 
     m = m_new;
     if ((tid & 7) == 0) alpha_s[i] = a;
     __syncthreads();
-    float al[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { al[e] = alpha_s[i0 + e]; o[e] *= al[e]; }
+    for (int e = 0; e < 8; ++e) o[e] *= alpha_s[i0 + e];
     for (int j = 0; j < GA_T; ++j) {
       const float vj = v[d2][j];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] += vj * p[i0 + e][j];
+      const float4 p0 = *reinterpret_cast<const float4*>(&pT[j][i0]), p1 = *reinterpret_cast<const float4*>(&pT[j][i0 + 4]);
+      o[0] += vj * p0.x; o[1] += vj * p0.y; o[2] += vj * p0.z; o[3] += vj * p0.w;
+      o[4] += vj * p1.x; o[5] += vj * p1.y; o[6] += vj * p1.z; o[7] += vj * p1.w;
     }
   }
   if ((tid & 7) == 0) {

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Dev tool: N whole-video scoring passes (the validation forward, (1, 10, T, 2049), eval) for rocprofv3; prints wall ms per pass alone.
+    python tools/prof_mgfn_eval.py [T=290] [N=20]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from anomaly_detection_on_video_amd.models.mgfn import MGFNConfig, MGFNForVideoAnomalyDetection  # noqa: E402
+from anomaly_detection_on_video_amd.weights import synth_module_state_dict  # noqa: E402
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 290
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+dev = "cuda:0"
+m = MGFNForVideoAnomalyDetection(MGFNConfig())
+m.load_state_dict(synth_module_state_dict(m))
+m = m.to(dev).eval()
+v = torch.rand(1, 10, T, 2049, device=dev)
+with torch.no_grad():
+    for _ in range(3):
+        m(video=v)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n):
+        m(video=v)
+    torch.cuda.synchronize()
+print(f"eval (1,10,{T},2049): {(time.perf_counter() - t) / n * 1e3:.3f} ms per pass alone")
