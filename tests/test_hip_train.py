@@ -456,6 +456,52 @@ def test_graphed_step_recaptures_after_lr_change_parameter_move_and_state_reload
     assert step.graph is None and step.captures == GraphedTrainStep.MAX_CAPTURES
 
 
+def test_trainer_feeds_the_captured_steps_input_buffers_in_place():
+    """runner.Trainer._feed_graph_inputs + GraphedTrainStep.inputs(): once the step is a graph, a (normal, abnormal) loader batch on the
+    HOST is copied straight into the graph's input buffers -- normal rows first, as src/runner.py:29-39's torch.cat orders them -- and the
+    step is replayed on them: same losses and parameters, bit for bit, as the eager loop fed through training_batch()."""
+    from anomaly_detection_on_video_amd.models.mgfn import MGFNConfig, MGFNForVideoAnomalyDetection
+    from anomaly_detection_on_video_amd.optim import HipAdam
+    from anomaly_detection_on_video_amd.runner import Trainer, VideoAnomalyDetectionRunner
+    from anomaly_detection_on_video_amd.train_graph import GraphedTrainStep
+
+    def make():
+        m = MGFNForVideoAnomalyDetection(MGFNConfig())
+        m.load_state_dict(synth_module_state_dict(m))
+        m = m.to(DEV).train()
+        ones = torch.ones(2, 32, device=DEV)
+        m.injected_keep = (ones, ones)
+        return m, HipAdam(m.parameters(), lr=1e-3, weight_decay=5e-4)
+
+    def host_batch(i):  # what the two train loaders yield: dicts of CPU tensors
+        v = mgfn_inputs(4, 32, 90 + i)
+        return ({"feature": v[:2], "anomaly": torch.zeros(2)}, {"feature": v[2:], "anomaly": torch.ones(2)})
+
+    m_e, opt_e = make()
+    eager = GraphedTrainStep(m_e, opt_e, eager_steps=1 << 30)
+    m_g, opt_g = make()
+    graphed = GraphedTrainStep(m_g, opt_g, eager_steps=2)
+    losses_e, losses_g, fed = [], [], []
+    for i in range(6):
+        batch = host_batch(i)
+        dev_batch = tuple({k: t.to(DEV) for k, t in d.items()} for d in batch)
+        losses_e.append(float(eager(*VideoAnomalyDetectionRunner.training_batch(dev_batch))))
+        ok = Trainer._feed_graph_inputs(graphed, batch)
+        fed.append(ok)
+        if ok:
+            losses_g.append(float(graphed(*graphed.inputs())))
+        else:
+            losses_g.append(float(graphed(*VideoAnomalyDetectionRunner.training_batch(dev_batch))))
+    assert fed == [False, False, False, True, True, True]  # (no graph before the capture in step 2's call)
+    assert graphed.replays == 4 and losses_g == losses_e, (losses_g, losses_e)
+    for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
+        assert torch.equal(a, b), k
+    # another batch shape is not written anywhere: the caller falls back to the device batch
+    odd = ({"feature": mgfn_inputs(1, 32, 5), "anomaly": torch.zeros(1)}, {"feature": mgfn_inputs(1, 32, 6), "anomaly": torch.ones(1)})
+    before = graphed.inputs()[0].clone()
+    assert Trainer._feed_graph_inputs(graphed, odd) is False and torch.equal(graphed.inputs()[0], before)
+
+
 def test_hip_adam_creates_state_only_for_parameters_with_gradients():
     """torch.optim.Adam initialises `state[p]` the first time p has a gradient; a frozen parameter never gets an entry, so the
     state_dict of a partly frozen model has the same keys under both optimizers (a checkpoint interchange requirement)."""
