@@ -172,3 +172,49 @@ def test_variable_length_stream_vs_oracle_under_strict(strict):
         ref = mgfn_oracle.mgfn_forward(video, msd).scores.reshape(-1)
         assert s.shape == (n,) and rel_err(s.cpu(), ref) < TOL
         s0 += n * crops
+
+
+def test_variable_length_stream_soak_ring_wraps_under_lanes(strict):
+    """A long variable-length stream on the three lanes (120 videos of 3 .. 23 clips x 2 crops, global batches of 6: the ring of 58
+    rows + mirror wraps ~60 times, batches straddle video ends, several videos may complete in one step): every video's scores must equal,
+    bit for bit, the scorer run directly on that video's rows cut from the gathered features in stream order -- i.e. the ring + mirror hand
+    every scoring pass exactly its own rows, whatever the lanes' interleaving -- and every T in 3 .. 23 goes through the any-T kernels."""
+    import random
+
+    from anomaly_detection_on_video_amd.i3d import I3Res50
+    from anomaly_detection_on_video_amd.models.mgfn import MGFNConfig, MGFNForVideoAnomalyDetection
+    from anomaly_detection_on_video_amd.pipeline import ExtractScoreStream
+
+    bb = I3Res50()
+    bb.load_state_dict(synth_i3d_state_dict())
+    bb = bb.eval().to(DEV)
+    sc = MGFNForVideoAnomalyDetection(MGFNConfig())
+    sc.load_state_dict(synth_module_state_dict(sc))
+    sc = sc.eval().to(DEV)
+    rng = random.Random(11)
+    clips, crops, lb = [rng.randint(3, 23) for _ in range(120)], 2, 6
+    total = sum(clips) * crops
+    steps = total // lb
+    base = synth_tensor("soak.x", (24, 3, 16, 32, 32), scale=2.0).to(DEV)  # 24 distinct clips, dealt by a running index
+    stream = ExtractScoreStream(bb, sc, clips_per_video=clips, ncrops=crops, local_batch=lb)
+    assert stream.ring_rows == 54 and stream.max_video_rows == 46
+    handles = []
+    for k in range(steps):
+        idx = torch.tensor([(k * lb + j) * 7 % 24 for j in range(lb)], device=DEV)
+        handles.append(stream.step_async(base[idx]))
+    stream.drain()
+    torch.cuda.synchronize()
+    rows = torch.cat([h.result()[0] for h in handles])
+    scored = [vs for h in handles for vs in h.result()[1]]
+    done, end = 0, 0
+    while end + clips[done] * crops <= steps * lb:
+        end += clips[done] * crops
+        done += 1
+    assert [v for v, _ in scored] == list(range(done)) and done >= 100
+    ref_stream = ExtractScoreStream(bb, sc, clips_per_video=clips, ncrops=crops, local_batch=lb)
+    s0 = 0
+    with torch.no_grad():
+        for (v, s), n in zip(scored, clips):
+            want = ref_stream._score_eager(rows[s0 : s0 + n * crops].view(n, crops, -1))
+            assert s.shape == (n,) and torch.isfinite(s).all() and torch.equal(s, want), v
+            s0 += n * crops
