@@ -54,6 +54,11 @@ class GraphedTrainStep:
         self._stamp: Optional[Tuple] = None  # what the graph baked in besides shapes: parameter addresses, optimizer scalars
         if overlap and torch.cuda.is_available():
             mgfn_ops.ensure_side_stream()  # (streams cannot be created inside a capture)
+        # The stream the step is captured on -- and on which the LAST eager step before a capture runs: the kernels' per-stream scratch
+        # (split-K counter blocks and workspaces that are zero-filled once when allocated and left zero by every launch,
+        # ops.zeroed_workspace / ops.splitk_counters) then exists at its final size before the capture starts.  Allocated inside a
+        # capture, every such zero-fill becomes a node of the graph and runs again on every replay (12 fills, ~120 MB, per step).
+        self._cap_stream: Optional[torch.cuda.Stream] = torch.cuda.Stream() if torch.cuda.is_available() else None
 
     def _step(self, video, al, nl) -> torch.Tensor:
         self.optimizer.zero_grad(set_to_none=True)
@@ -111,7 +116,14 @@ class GraphedTrainStep:
             return self.loss
         if self.eager_left > 0 or self.graph is not None or not self.model.training:
             self.eager_left -= 1
-            loss = self._step(video, abnormal_labels, normal_labels).detach()
+            if self.eager_left == 0 and self.graph is None and self.model.training and self._cap_stream is not None:
+                # the last eager step before a capture: on the capture stream (see __init__), fenced by device-wide synchronisations
+                torch.cuda.synchronize()
+                with torch.cuda.stream(self._cap_stream):
+                    loss = self._step(video, abnormal_labels, normal_labels).detach()
+                torch.cuda.synchronize()
+            else:
+                loss = self._step(video, abnormal_labels, normal_labels).detach()
             self._finish()
             return loss
         # capture (records, does not run), then replay on this batch
@@ -120,7 +132,7 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.optimizer.zero_grad(set_to_none=True)  # the captured backward allocates the gradients in the graph's pool
         graph = torch.cuda.CUDAGraph()
-        with mgfn_ops.hold_plans() as held, torch.cuda.graph(graph):
+        with mgfn_ops.hold_plans() as held, torch.cuda.graph(graph, stream=self._cap_stream):
             loss = self._step(*self.static)
         self.graph, self.loss = graph, loss.detach()
         self.held_plans, self._stamp = held, self._baked()
