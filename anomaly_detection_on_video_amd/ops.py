@@ -261,9 +261,11 @@ def conv_pool_out_dims(in_thw: Sequence[int], pc: "PackedConv", pool_kernel, poo
 # The fused stem can gather 16-byte pieces from column-parity planes of its input (advhip.h: advhip_conv3d_s2w_*): the conv
 # launch is 6.5 % faster (2.25 vs 2.41 ms at B = 32), the planes cost a pass over the input (0.145 ms for an fp32 NCDHW
 # tensor).  For resized uint8 frames the TenCrop / normalise pass writes the planes itself, so that path uses them by default
-# (U8_STEM_FORM "planes"); for an fp32 NCDHW input the extra pass cancels the gain in isolation and adds 0.6 GB of HBM
-# traffic per step for +0.3 % in the three-lane stream: opt-in (ADV_STEM_S2W=1).
-STEM_S2W = os.environ.get("ADV_STEM_S2W", "0") == "1"
+# (U8_STEM_FORM "planes"); for an fp32 NCDHW input the extra pass cancels the gain in isolation and adds 0.7 GB of HBM
+# traffic per step; in the three-lane stream it buys +0.4 % on the 20-step line and +0.7 % sustained (round 5, four alternating
+# runs on one box: 3 796 -> 3 812 and 3 846 -> 3 872 clips/s; round 3 on its kernels: +0.3 %), bit-identical features: ON by
+# default since round 5 (ADV_STEM_S2W=0: the 4-byte gather straight from the NCDHW tensor).
+STEM_S2W = os.environ.get("ADV_STEM_S2W", "1") == "1"
 
 
 def s2w_ok(pc: PackedConv, W: int) -> bool:

@@ -25,7 +25,7 @@ def forward_end(name):
 
 
 def family(name):
-    if "conv3d_igemm" in name or "splitk_reduce" in name:
+    if "conv3d_igemm" in name or "splitk_reduce" in name or "split_w" in name:  # (split_w: the stem's column-parity planes pass)
         return "conv"
     if "maxpool" in name or "avgpool" in name or "stem_pool_merge" in name:
         return "pool"

@@ -89,7 +89,17 @@ def one_chain(seg):
             convs[-1][0] += float(r["Counter_Value"])
             convs[-1][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
             convs[-1][2] += " +reduce"
-    return convs
+        elif "split_w_kernel" in n:  # the stem's column-parity planes pass (ADV_STEM_S2W, default since round 5): billed to conv1
+            pending = [float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])]
+            convs.append([pending[0], pending[1], "split_w + "])
+            convs[-1].append("merge-next")
+    out = []
+    for c in convs:  # fold a split_w entry into the conv launch that follows it
+        if out and len(out[-1]) == 4:
+            head = out.pop()
+            c = [c[0] + head[0], c[1] + head[1], head[2] + c[2]]
+        out.append(c)
+    return out
 
 
 def main():
