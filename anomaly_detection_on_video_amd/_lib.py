@@ -25,6 +25,7 @@ ALGO_IGEMM_128x128x32 = 5
 ALGO_IGEMM_128x64x32 = 6
 ALGO_IGEMM_64x64x32 = 7
 ALGO_IGEMM_64x128x32 = 8
+ALGO_IGEMM_256x64 = 9  # 256 x 64 x 16, four waves stacked along M; the 2-deep LDS-DMA family only
 ALGO_FAST_BASE = 32  # + tile id: scalar-offset / tap-mask gather (<= 32 taps)
 IGEMM_ALGOS = (1, 2, 3, 4, 5, 6, 7, 8)
 FAST_ALGOS = tuple(ALGO_FAST_BASE + a for a in IGEMM_ALGOS)
@@ -35,7 +36,7 @@ DMA4_ALGOS = tuple(ALGO_DMA4_BASE + a for a in (2, 3, 4))
 ALGO_BF16X3_BASE = 128  # + tile id 5 (128x128x32) / 6 (128x64x32): opt-in split-bf16 arithmetic (3 bf16 MFMAs per fragment)
 BF16X3_ALGOS = tuple(ALGO_BF16X3_BASE + a for a in (5, 6))
 ALGO_DMA2_BASE = 160  # + tile id: LDS-DMA kernel, 2-deep ring (less LDS, more resident workgroups)
-DMA2_ALGOS = tuple(ALGO_DMA2_BASE + a for a in (1, 2, 3, 4, 6, 7, 8))
+DMA2_ALGOS = tuple(ALGO_DMA2_BASE + a for a in (1, 2, 3, 4, 6, 7, 8, 9))
 ALGO_TSPAN_128x64 = 192  # (kt,1,1) convs: 128x64 tile of 2 or 4 frames x flattened spatial positions
 ALGO_PERSIST_BASE = 224  # + tile id (2: 128x64, 3: 64x64) + 8 * (workgroups per CU - 1), 1..3: persistent wave-specialised kernel (opt-in), unsplit 1x1x1 stride-1 convs, K >= 64
 PERSIST_ALGOS = tuple(ALGO_PERSIST_BASE + t + 8 * (w - 1) for w in (1, 2, 3) for t in (2, 3))
@@ -47,6 +48,8 @@ def algo_tile(algo: int):
         return (128, 64, 16)
     if ALGO_PERSIST_BASE <= algo < ALGO_PERSIST_BASE + 32:
         return (128 if (algo - ALGO_PERSIST_BASE) & 7 == 2 else 64, 64, 16)
+    if algo == ALGO_DMA2_BASE + ALGO_IGEMM_256x64:
+        return (256, 64, 16)
     if algo >= ALGO_DMA2_BASE:
         algo -= ALGO_DMA2_BASE
     if algo >= ALGO_BF16X3_BASE:

@@ -158,8 +158,13 @@ __device__ __forceinline__ void vec_store(float* p, const float (&v)[VW]) {
 
 template <int BM, int BN, int BK>
 struct IgemmCfg {
-  static constexpr int FM = BM / 32, FN = BN / 32;  // 16x16 fragments per wave along M / N
-  static constexpr int WM = BM / 2, WN = BN / 2;    // wave tile (2 x 2 waves)
+  // the four waves of a workgroup as WAVES_M x WAVES_N: 2 x 2, or 4 x 1 for the 256-row tile (a 64 x 64 wave tile -- the 64
+  // accumulators, b128 A and B fragment reads and the epilogue staging of the 128 x 128 tile's waves -- over a 64-wide N)
+  static constexpr int WAVES_M = BM == 256 ? 4 : 2, WAVES_N = 4 / WAVES_M;
+  static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
+  static constexpr int FM = WM / 16, FN = WN / 16;            // 16x16 fragments per wave along M / N
+  __device__ static __forceinline__ int wave_m(int wave) { return WAVES_N == 1 ? wave : wave >> 1; }
+  __device__ static __forceinline__ int wave_n(int wave) { return WAVES_N == 1 ? 0 : wave & 1; }
   static constexpr int KR = 256 / BM;               // k-rows covered by one pass of the 256 threads
   static constexpr int RA = BK / KR;                // A elements gathered per thread per k-tile
   static constexpr int RB = BK * BN / 4 / 256;      // float4 of B per thread per k-tile
@@ -206,12 +211,12 @@ __device__ __forceinline__ float act_dact(int code, float op) { return code == A
 enum EpiMode { EM_PLAIN = 0, EM_RES = 1, EM_DACT = 2, EM_GELU = 3, EM_MUL = 4, EM_GELU2 = 5 };
 
 template <int BM, int BN, int BK, int MODE>
-__device__ __forceinline__ void igemm_epilogue_plain(const ConvArgs& a, f32x4 (&acc)[BM / 32][BN / 32], float* smem, int m0, int n0, int wave, int lane) {
+__device__ __forceinline__ void igemm_epilogue_plain(const ConvArgs& a, f32x4 (&acc)[IgemmCfg<BM, BN, BK>::FM][IgemmCfg<BM, BN, BK>::FN], float* smem, int m0, int n0, int wave, int lane) {
   using Cfg = IgemmCfg<BM, BN, BK>;
   constexpr int FM = Cfg::FM, FN = Cfg::FN;
   constexpr bool OPERAND = MODE == EM_RES || MODE == EM_DACT || MODE == EM_MUL;
   constexpr bool SECOND = MODE == EM_GELU || MODE == EM_GELU2;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = Cfg::wave_m(wave), wn = Cfg::wave_n(wave);
   const int li = lane & 15, lg = lane >> 4;
   float* st = smem + wave * (16 * Cfg::ST_STRIDE);
   const bool relu = a.relu == 1;
@@ -352,11 +357,11 @@ __device__ __forceinline__ void igemm_epilogue_plain(const ConvArgs& a, f32x4 (&
 // accumulator element acc[jm][jn][r] of lane (li, lg):
 //   m = m0 + wm*WM + FM*(4*lg + r) + jm,   n = n0 + wn*WN + FN*li + jn
 template <int BM, int BN, int BK>
-__device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[BM / 32][BN / 32], float* smem, int split,
+__device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, f32x4 (&acc)[IgemmCfg<BM, BN, BK>::FM][IgemmCfg<BM, BN, BK>::FN], float* smem, int split,
                                                int m0, int n0, int wave, int lane, bool fused) {
   using Cfg = IgemmCfg<BM, BN, BK>;
   constexpr int FM = Cfg::FM, FN = Cfg::FN;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = Cfg::wave_m(wave), wn = Cfg::wave_n(wave);
   const int li = lane & 15, lg = lane >> 4;
   const int b_col = wn * Cfg::WN + FN * li;
   if (fused && !a.ln_u) {  // (uniform: kernel arguments)
@@ -1130,11 +1135,15 @@ __device__ __forceinline__ void lds_wait(Frag<NA>& a, Frag<NB>& b) {
 // epilogue (in-kernel stamps: ~12 of 66 us per tile at K = 768), so one more resident workgroup per CU
 // is worth more than spare registers: without the attribute hipcc allocates 51 VGPR + 36 AGPR for the
 // 64x64x16 kernel (5 waves/SIMD) although LDS admits 6.
+#ifndef ADVHIP_T256_WAVES
+#define ADVHIP_T256_WAVES 2
+#endif
 template <int BM, int BN, int BK, int NS>
 constexpr int dma_waves_per_simd() {
   constexpr int ring = NS * BK * (BM + BN), st = IgemmCfg<BM, BN, BK>::ST_FLOATS;
   constexpr int lds_bytes = (ring > st ? ring : st) * 4;
   constexpr int by_lds = 163840 / lds_bytes;  // 256-thread workgroups = one wave per SIMD each
+  if (BM == 256) return by_lds < ADVHIP_T256_WAVES ? by_lds : ADVHIP_T256_WAVES;  // (study knob; the 40-KB ring admits 4)
   if (BM * BN >= 128 * 128) return by_lds < 2 ? by_lds : 2;  // 64 accumulators: 3 waves would spill
   return by_lds > 8 ? 8 : (by_lds < 1 ? 1 : by_lds);
 }
@@ -1338,7 +1347,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   const int rsel = lane / (BM / 4); // which of the instruction's k-rows this lane fills
   const int rm[4] = {rsel == 0 ? -1 : 0, rsel == 1 ? -1 : 0, rsel == 2 ? -1 : 0, rsel == 3 ? -1 : 0};
   if constexpr (AMODE == 1) {
-    static_assert(AMODE == 0 || (BK == 16 && NS == 2 && CHECK && !U8 && (BM == 128 || BM == 64) &&
+    static_assert(AMODE == 0 || (BK == 16 && NS == 2 && CHECK && !U8 && (BM == 256 || BM == 128 || BM == 64) &&
                                  (EPI == EPI_STD || ((EPI == EPI_POOL233 || EPI == EPI_TSPAN2 || EPI == EPI_TSPAN4) && BM == 128))),
                   "16-byte gather pieces: the fused stem (column-parity planes), the T-spanning tiles and plain tiles of (kt,1,1) convs");
     const int ml4 = (lane % (BM / 4)) * 4;
@@ -1416,7 +1425,10 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
       for (int q = 0; q < S_NI; ++q) {
         const int g = wave * S_NI + q;
         int eo, eb;
-        if constexpr (S_RPI == 2) {
+        if constexpr (S_RPI == 1) {  // (BM = 256: an instruction's 64 lanes are one k-row)
+          eo = ent[2 * q];
+          eb = ent[2 * q + 1];
+        } else if constexpr (S_RPI == 2) {
           eo = rsel ? ent[4 * q + 2] : ent[4 * q];
           eb = rsel ? ent[4 * q + 3] : ent[4 * q + 1];
         } else {
@@ -1472,7 +1484,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
     issue_part(k0, stage, 0, 1);
   };
 
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = Cfg::wave_m(wave), wn = Cfg::wave_n(wave);
   const int li = lane & 15, lg = lane >> 4;
   const int a_col = wm * Cfg::WM + FM * li;
   const int b_col = wn * Cfg::WN + FN * li;
@@ -2898,6 +2910,7 @@ static int persist_wgs_per_cu(int algo) { return ((algo - ADVHIP_ALGO_PERSIST_BA
 static void tile_of(int algo, int* BM, int* BN, int* BK) {
   if (algo == ADVHIP_ALGO_TSPAN_128x64) { *BM = 128; *BN = 64; *BK = 16; return; }
   if (is_persist(algo)) { *BM = persist_tile(algo) == ADVHIP_ALGO_IGEMM_128x64 ? 128 : 64; *BN = 64; *BK = 16; return; }
+  if (algo == ADVHIP_ALGO_DMA2_BASE + ADVHIP_ALGO_IGEMM_256x64) { *BM = 256; *BN = 64; *BK = 16; return; }
   if (algo >= ADVHIP_ALGO_DMA2_BASE) algo -= ADVHIP_ALGO_DMA2_BASE;
   if (algo >= ADVHIP_ALGO_BF16X3_BASE) algo -= ADVHIP_ALGO_BF16X3_BASE;
   if (algo >= ADVHIP_ALGO_DMA4_BASE) algo -= ADVHIP_ALGO_DMA4_BASE;
@@ -2916,6 +2929,7 @@ static bool instantiated(int algo) {
   if (algo >= ADVHIP_ALGO_PERSIST_BASE) return is_persist(algo) && (persist_tile(algo) == ADVHIP_ALGO_IGEMM_128x64 || persist_tile(algo) == ADVHIP_ALGO_IGEMM_64x64) && persist_wgs_per_cu(algo) <= 3;
   auto tile_in = [](int t, unsigned mask) { return t >= 1 && t <= 8 && ((mask >> t) & 1u); };
   constexpr unsigned ALL = 0x1FEu, NO5 = ALL & ~(1u << 5);
+  if (algo == ADVHIP_ALGO_DMA2_BASE + ADVHIP_ALGO_IGEMM_256x64) return true;
   if (algo >= ADVHIP_ALGO_DMA2_BASE) return tile_in(algo - ADVHIP_ALGO_DMA2_BASE, NO5);
   if (algo >= ADVHIP_ALGO_BF16X3_BASE) return tile_in(algo - ADVHIP_ALGO_BF16X3_BASE, (1u << 5) | (1u << 6));
   if (algo >= ADVHIP_ALGO_DMA4_BASE) return tile_in(algo - ADVHIP_ALGO_DMA4_BASE, (1u << 2) | (1u << 3) | (1u << 4));
@@ -3173,7 +3187,7 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
   long long Mv = M;
   bool a16pad = false;
   if (nocheck && d->st == 1 && d->sh == 1 && d->sw == 1 && a.THW % 4 != 0 && ((uintptr_t)x & 15) == 0 && c.splits == 1 &&
-      ((c.algo > ADVHIP_ALGO_DMA2_BASE && c.algo <= ADVHIP_ALGO_DMA2_BASE + 8) || is_persist(c.algo)) && !ln && y_preact == nullptr && dact_z == nullptr) {
+      ((c.algo > ADVHIP_ALGO_DMA2_BASE && c.algo <= ADVHIP_ALGO_DMA2_BASE + ADVHIP_ALGO_IGEMM_256x64) || is_persist(c.algo)) && !ln && y_preact == nullptr && dact_z == nullptr) {
     a.MP = (a.THWo + 3) / 4 * 4;
     Mv = (long long)d->B * a.MP;
     if (Mv < (1ll << 31)) {
@@ -3294,6 +3308,7 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
       break;
     ADVHIP_DMA2_CASE(ADVHIP_ALGO_IGEMM_128x128, 128, 128, 16)
     ADVHIP_DMA2_CASE(ADVHIP_ALGO_IGEMM_128x64, 128, 64, 16)
+    ADVHIP_DMA2_CASE(ADVHIP_ALGO_IGEMM_256x64, 256, 64, 16)
     ADVHIP_DMA2_CASE(ADVHIP_ALGO_IGEMM_64x64, 64, 64, 16)
     ADVHIP_DMA2_CASE(ADVHIP_ALGO_IGEMM_64x128, 64, 128, 16)
     ADVHIP_DMA2_CASE(ADVHIP_ALGO_IGEMM_128x64x32, 128, 64, 32)

@@ -72,45 +72,67 @@ __global__ void mil_magnitude_bwd_kernel(const float* __restrict__ feat, const f
   if (lane == 0 && d_sc) d_scores[w] += d_sc[(size_t)b * T + t] / (float)ncrops;
 }
 
-// one wavefront per video: k rounds of wave-wide arg-max (ties -> lowest index)
-__global__ void mil_topk_kernel(const float* __restrict__ mag, const float* __restrict__ keep,
-                                const float* __restrict__ sc, long long* __restrict__ idx, float* __restrict__ score,
-                                int n, int T, int k) {
-  const int lane = threadIdx.x & 63;
-  const int v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (v >= n) return;
-  const float* m = mag + (size_t)v * T;
-  const float* kp = keep ? keep + (size_t)v * T : nullptr;
-  unsigned long long taken = 0ull;  // bit i: this lane's i-th element (t = lane + 64 i) already selected
+// ---- arg-max order of torch.topk: NaN is the largest value, then the larger value, then (ties) the lower index.
+constexpr int MIL_NONE = 0x7fffffff;  // "no candidate yet"
+__device__ __forceinline__ bool mil_better(float ov, int oi, float bv, int bi) {
+  if (oi == MIL_NONE) return false;
+  if (bi == MIL_NONE) return true;
+  const bool o_nan = ov != ov, b_nan = bv != bv;
+  if (o_nan != b_nan) return o_nan;
+  if (!o_nan && ov != bv) return ov > bv;
+  return oi < bi;
+}
+
+// One workgroup of W wavefronts per video, any T: k rounds of arg-max.  A round scans the row with the <= 15 indices already
+// chosen excluded (kept in LDS, read as a broadcast: k <= 16, so the list replaces a per-element "taken" bitmap and T has no
+// bound but int32), reduces within each wave by xor-shuffle and across the W waves through LDS in wave order.  W = 1 for the
+// training shapes (T = 32 segments), 4 / 16 for whole-video validation (T = n_clips, /root/reference/src/runner.py:42-50 ->
+// modeling_mgfn.py:345-346 -- torch.topk has no length limit and neither does this).
+template <int W>
+__global__ __launch_bounds__(64 * W) void mil_topk_kernel(const float* __restrict__ mag, const float* __restrict__ keep,
+                                                          const float* __restrict__ sc, long long* __restrict__ idx,
+                                                          float* __restrict__ score, int T, int k) {
+  __shared__ int chosen[16];
+  __shared__ float w_best[W];
+  __shared__ int w_bi[W];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t v = blockIdx.x;
+  const float* m = mag + v * T;
+  const float* kp = keep ? keep + v * T : nullptr;
   float ssum = 0.f;
   for (int j = 0; j < k; ++j) {
     float best = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int t = lane, i = 0; t < T; t += 64, ++i) {
-      if ((taken >> i) & 1ull) continue;
+    int bi = MIL_NONE;
+    for (int t = threadIdx.x; t < T; t += 64 * W) {
+      bool skip = false;
+      for (int q = 0; q < j; ++q) skip |= chosen[q] == t;
+      if (skip) continue;
       const float val = kp ? m[t] * kp[t] : m[t];
-      // NaN sorts as the largest value, as torch.topk does
-      const bool gt = (val > best) || (val != val && best == best) || (bi == 0x7fffffff);
-      if (gt) { best = val; bi = t; }
+      if (mil_better(val, t, best, bi)) { best = val; bi = t; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       const float ob = __shfl_xor(best, off, 64);
       const int oi = __shfl_xor(bi, off, 64);
-      const bool o_nan = ob != ob, b_nan = best != best;
-      bool take;
-      if (oi == 0x7fffffff) take = false;
-      else if (bi == 0x7fffffff) take = true;
-      else if (o_nan != b_nan) take = o_nan;
-      else if (!o_nan && ob != best) take = ob > best;
-      else take = oi < bi;
-      if (take) { best = ob; bi = oi; }
+      if (mil_better(ob, oi, best, bi)) { best = ob; bi = oi; }
     }
-    if ((bi & 63) == lane) taken |= 1ull << (bi >> 6);
-    ssum += sc[(size_t)v * T + bi];
-    if (lane == 0) idx[(size_t)v * k + j] = bi;
+    if (W > 1) {
+      if (lane == 0) { w_best[wave] = best; w_bi[wave] = bi; }
+      __syncthreads();
+      best = w_best[0];
+      bi = w_bi[0];
+#pragma unroll
+      for (int w = 1; w < W; ++w)
+        if (mil_better(w_best[w], w_bi[w], best, bi)) { best = w_best[w]; bi = w_bi[w]; }
+    }
+    ssum += sc[v * T + bi];
+    if (threadIdx.x == 0) {
+      chosen[j] = bi;
+      idx[v * k + j] = bi;
+    }
+    __syncthreads();  // chosen[j] is visible to the next round's scan; w_best / w_bi may be rewritten
   }
-  if (lane == 0) score[v] = ssum / (float)k;
+  if (threadIdx.x == 0) score[v] = ssum / (float)k;
 }
 
 // gather: one block per (video v, crop c, j); copies F floats
@@ -176,9 +198,14 @@ extern "C" int advhip_mil_topk_select_f32(const float* mag, const float* keep, c
                                           int32_t F, int32_t k, void* stream) {
   ADVHIP_REQUIRE(mag && sc && features && idx && sel && score, "mil_topk_select: null pointer");
   ADVHIP_REQUIRE(n > 0 && ncrops > 0 && F > 0, "mil_topk_select: bad shape");
-  ADVHIP_REQUIRE(k > 0 && k <= 16 && k <= T && T <= 4096, "mil_topk_select: need 0 < k <= min(16, T), T <= 4096 (k=%d T=%d)", k, T);
-  hipLaunchKernelGGL(mil_topk_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, mag, keep, sc,
-                     reinterpret_cast<long long*>(idx), score, n, T, k);
+  ADVHIP_REQUIRE(k > 0 && k <= 16 && k <= T, "mil_topk_select: need 0 < k <= min(16, T) (k=%d T=%d)", k, T);
+  long long* idx_ll = reinterpret_cast<long long*>(idx);
+  if (T <= 2048)
+    hipLaunchKernelGGL(mil_topk_kernel<1>, dim3(n), dim3(64), 0, (hipStream_t)stream, mag, keep, sc, idx_ll, score, T, k);
+  else if (T <= 32768)
+    hipLaunchKernelGGL(mil_topk_kernel<4>, dim3(n), dim3(256), 0, (hipStream_t)stream, mag, keep, sc, idx_ll, score, T, k);
+  else
+    hipLaunchKernelGGL(mil_topk_kernel<16>, dim3(n), dim3(1024), 0, (hipStream_t)stream, mag, keep, sc, idx_ll, score, T, k);
   if (int rc = check_launch("mil_topk")) return rc;
   hipLaunchKernelGGL(mil_gather_kernel, dim3(n * ncrops * k), dim3(256), 0, (hipStream_t)stream, features,
                      reinterpret_cast<const long long*>(idx), sel, n, ncrops, T, F, k);

@@ -450,8 +450,10 @@ class MGFNForVideoAnomalyDetection(MGFNPreTrainedModel):
         elif self.training:
             # same call order as the reference: abnormal first, then normal (modeling_mgfn.py:364-372)
             h = batch_size // 2 if split else batch_size
-            # (ONE dropout call for both masks, rows [0, h) the abnormal call's and [h, 2h) the normal one's: the draws of the reference's
-            # two calls in its order, two launches instead of four)
+            # (ONE dropout call for both masks, rows [0, h) the abnormal half's and [h, 2h) the normal half's -- two launches instead of
+            # four.  Same distribution as the reference's two calls (iid Bernoulli(0.3) / 0.3 per element), NOT the same draws: one
+            # 2h x T Philox call maps elements to random numbers differently from two h x T calls, so a seed-for-seed comparison of
+            # training masks with the reference is not offered; parity of this branch is pinned with `injected_keep` instead.)
             keep = self.dropout(torch.ones((2 * h, mag.shape[1]), device=mag.device, dtype=mag.dtype))
             keep_a, keep_n = keep[:h], keep[h:]
         else:

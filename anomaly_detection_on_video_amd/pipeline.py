@@ -10,7 +10,8 @@ clip-level anomaly scores.
 from __future__ import annotations
 
 import os
-from typing import Dict, List, Optional, Sequence, Tuple, Union
+from collections import OrderedDict
+from typing import List, Optional, Sequence, Tuple, Union
 
 import torch
 
@@ -36,6 +37,9 @@ class ExtractScoreStream:
     /root/reference/extract_features.py:93-100, 104-110; UCF-Crime: 50..500 clips).  A global batch may end one video and begin the
     next; every video is scored with T = its own clip count (runner.py:42-50)."""
 
+    GRAPH_CACHE_MAX = 8      # captured scoring passes kept (ADV_SCORE_GRAPH=1), per distinct video length
+    SCORED_LOG_MAX = 4096    # entries of scored_log kept
+
     def __init__(self, backbone, scorer, clips_per_video: Union[int, Sequence[int]] = 32, ncrops: int = 10, local_batch: int = 32,
                  world: int = 1, rank: int = 0, feat_dim: int = 2048):
         self.backbone, self.scorer = backbone, scorer
@@ -58,12 +62,15 @@ class ExtractScoreStream:
         self._vid_start = 0  # ... and the stream position of its first row
         self.pos = 0  # global stream position (crop-clips consumed so far)
         self.videos_scored = 0
-        self.scored_log: List[Tuple[int, int]] = []  # (video, its clip count) of every video this rank scored
+        # (video, its clip count) of the last SCORED_LOG_MAX videos this rank scored (a bounded record: the stream may run for days)
+        self.scored_log: List[Tuple[int, int]] = []
         self.last_scores: Optional[torch.Tensor] = None
         # eval scoring of one video is ~200 tiny launches; ADV_SCORE_GRAPH=1 replays it as one hipGraph
         # (opt-in: measured neutral on throughput, the launches already overlap the backbone)
         self.use_graph = os.environ.get("ADV_SCORE_GRAPH") == "1"
-        self._graphs: Dict[Tuple[int, int, int], Tuple[torch.cuda.CUDAGraph, torch.Tensor, torch.Tensor]] = {}
+        # one captured pass per video SHAPE, least recently used first; at most GRAPH_CACHE_MAX of them are kept (each holds its
+        # static input / output and a private activation pool: a variable-length stream would otherwise grow without bound)
+        self._graphs: "OrderedDict[Tuple[int, int, int], Tuple[torch.cuda.CUDAGraph, torch.Tensor, torch.Tensor]]" = OrderedDict()
         # step_async: consecutive steps alternate between `lanes` HIP streams (see step_async)
         # (measured at B=32 on one MI355X: 1 lane + batch split over 2 streams 10.12 ms/step, 2 lanes 9.96, 3 lanes 9.65,
         #  4 lanes 10.06, 6 lanes 9.89; lanes x an in-step batch split is slower than lanes alone)
@@ -246,6 +253,8 @@ class ExtractScoreStream:
                 self._after_ring_read = hook  # the ring is free for the next step once the last video has been read
             scored.append((v, self.score_video(vid)))
             self.scored_log.append((v, n // self.ncrops))
+            if len(self.scored_log) > self.SCORED_LOG_MAX:
+                del self.scored_log[: len(self.scored_log) - self.SCORED_LOG_MAX]
         return scored
 
     @torch.no_grad()
@@ -266,12 +275,15 @@ class ExtractScoreStream:
             entry = self._graphs.get(key)
             if entry is None:
                 static_in = feats.clone()
-                self._score_eager(static_in)  # warm-up outside capture (lazy initialisation, rocBLAS handles)
+                self._score_eager(static_in)  # warm-up outside capture (lazily built operands: gather tables, packed / folded weights)
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     static_out = self._score_eager(static_in)
                 entry = self._graphs[key] = (graph, static_in, static_out)
+                while len(self._graphs) > self.GRAPH_CACHE_MAX:
+                    self._graphs.popitem(last=False)
+            self._graphs.move_to_end(key)
             graph, static_in, static_out = entry
             static_in.copy_(feats)
             self._ring_read_issued()

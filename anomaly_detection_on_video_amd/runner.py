@@ -333,6 +333,11 @@ class Trainer:
         if (af.shape != nf.shape or (2 * b,) + tuple(nf.shape[1:]) != tuple(video.shape) or tuple(al.shape) != tuple(s_al.shape)
                 or tuple(nl.shape) != tuple(s_nl.shape)):
             return False
+        if any(src.dtype != dst.dtype or (src.is_cuda and src.device != dst.device)
+               for src, dst in ((nf, video), (af, video), (al, s_al), (nl, s_nl))):
+            return False  # copy_ would cast silently; the general path runs such a batch as given
+        # these copies are issued on the CURRENT stream, the one graph.replay() is issued on right after (GraphedTrainStep.__call__):
+        # stream order is what makes the replay see them
         video[:b].copy_(nf, non_blocking=True)
         video[b:].copy_(af, non_blocking=True)
         s_al.copy_(al, non_blocking=True)

@@ -115,7 +115,8 @@ class GraphedTrainStep:
             self._finish()
             return self.loss
         if self.eager_left > 0 or self.graph is not None or not self.model.training:
-            self.eager_left -= 1
+            if self.model.training:  # only a TRAINING step is the warm step a capture needs (an eval call must not use it up)
+                self.eager_left -= 1
             if self.eager_left == 0 and self.graph is None and self.model.training and self._cap_stream is not None:
                 # the last eager step before a capture: on the capture stream (see __init__), fenced by device-wide synchronisations
                 torch.cuda.synchronize()

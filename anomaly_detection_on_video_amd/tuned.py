@@ -22,6 +22,11 @@ def table() -> Dict[str, Tuple[int, int]]:
             if os.environ.get("ADV_ARITH") == "mixed" and os.path.exists(mixed):
                 with open(mixed) as f:
                     _TABLE.update({k: (int(v[0]), int(v[1])) for k, v in json.load(f).items()})
+            # ADV_TUNED_OVERLAY=path.json (experiment knob): entries that replace the committed ones for an A/B on one box
+            overlay = os.environ.get("ADV_TUNED_OVERLAY", "")
+            if overlay:
+                with open(overlay) as f:
+                    _TABLE.update({k: (int(v[0]), int(v[1])) for k, v in json.load(f).items()})
     return _TABLE
 
 

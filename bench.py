@@ -23,6 +23,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# launches of the conv stack per forward: the reference's 53 Conv3d as 52 conv launches (layer1.0's conv3 + downsample are one GEMM over
+# [x ; h]), the stem's column-parity planes pass in front (ADV_STEM_S2W=1) and the pooled stem's merge pass behind it
+CONV_LAUNCHES = "52 conv launches for the 53 Conv3d + the stem's planes pass + its pool-merge pass"
 GFLOP_PER_CLIP = 32.829145088  # 2 x 16.414572544 GMAC, 53 bias-free Conv3d (oracle.conv_macs)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 
@@ -106,14 +109,26 @@ def launch_ranks(n: int, argv) -> int:
            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    env.setdefault("NCCL_DEBUG", "WARN")               # RCCL's own account of a failed communicator setup goes to the ranks' stderr
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
     if proc.returncode != 0 or len(lines) != 1:
+        # a failed first contact must be attributable: the ranks' output, RCCL's warnings and the environment it ran under
         sys.stderr.write(proc.stdout[-4000:])
-        sys.stderr.write(f"\nbench.py: {n}-rank launch failed (exit {proc.returncode}, {len(lines)} result lines)\n")
+        sys.stderr.write("\n---- ranks' stderr (tail) ----\n" + proc.stderr[-6000:])
+        sys.stderr.write(f"\nbench.py: {n}-rank launch failed (exit {proc.returncode}, {len(lines)} result lines); env: {json.dumps(comm_env(env))}\n")
         return proc.returncode or 1
+    sys.stderr.write(proc.stderr[-2000:])
     print(lines[0], flush=True)
     return 0
+
+
+def comm_env(env=None) -> dict:
+    """The environment variables that decide how the ranks talk to each other (recorded in the N > 1 line and in a failed launch's tail)."""
+    env = os.environ if env is None else env
+    keys = ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "NCCL_SOCKET_IFNAME", "NCCL_IB_DISABLE", "NCCL_P2P_DISABLE", "RCCL_MSCCL_ENABLE", "HIP_VISIBLE_DEVICES",
+            "ROCR_VISIBLE_DEVICES", "MASTER_ADDR", "MASTER_PORT", "ADV_BENCH_SHARE_GPU", "ADV_PIPELINE_LANES")
+    return {k: env[k] for k in keys if k in env}
 
 
 def cpu_model() -> str:
@@ -573,6 +588,10 @@ def main():
                 "rank_clips_per_s_min": round(args.batch * args.steps / max(rank_elapsed), 2),
                 "rank_clips_per_s_max": round(args.batch * args.steps / min(rank_elapsed), 2),
                 "arith": aops.ARITH,
+                # which form of the stem ran on this fp32 NCDHW input: "planes" = one split_w pass writes column-parity planes, the stem
+                # gathers 16-byte pieces from them (ADV_STEM_S2W=1, the default); "ncdhw" = 4-byte gather straight from the input
+                "stem_form": "planes" if aops.STEM_S2W else "ncdhw",
+                **({"env": comm_env()} if world > 1 else {}),
             },
             "roofline": {
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -581,8 +600,8 @@ def main():
                 "hbm_gbps": None if traffic is None else round(traffic / (conv_ms_avg * 1e-3) / 1e9, 1), "hbm_peak_gbps": 8000.0,
                 "traffic_unit": "bytes per launch set (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes in profiles/)",
                 "traffic_source": traffic_src,
-                "kernel": "conv3d fp32-MFMA stack (53 launches per step on rank 0)" if not overlapped else
-                f"conv3d fp32-MFMA stack ({53 * n_streams} launches per step on rank 0; steps alternate between {stream.lanes} HIP stream lanes, "
+                "kernel": f"conv3d fp32-MFMA stack ({CONV_LAUNCHES} per step on rank 0)" if not overlapped else
+                f"conv3d fp32-MFMA stack ({CONV_LAUNCHES} per step and stream, {n_streams} stream(s) per step on rank 0; steps alternate between {stream.lanes} HIP stream lanes, "
                 f"batch split over {n_streams} stream(s) per step; time = first start .. last end over the K steps / K, pools + scoring included)",
                 "flop_per_launch_set": args.batch * GFLOP_PER_CLIP * 1e9, "avg_ms_per_launch_set": round(conv_ms_avg, 4),
             },

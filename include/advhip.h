@@ -42,6 +42,7 @@ extern "C" {
 #define ADVHIP_ALGO_IGEMM_128x64x32 6
 #define ADVHIP_ALGO_IGEMM_64x64x32 7
 #define ADVHIP_ALGO_IGEMM_64x128x32 8
+#define ADVHIP_ALGO_IGEMM_256x64 9 /* 256(M) x 64(N) x 16: four waves stacked along M (64 x 64 wave tiles); ADVHIP_ALGO_DMA2_BASE only */
 /* + tile id 1..8: same tiles, gather arithmetic hoisted to scalar offsets + coordinate bit-mask (kernel <= 10^3) */
 #define ADVHIP_ALGO_FAST_BASE 32
 /* + tile id: the fast gather with LDS-DMA operand staging into a 3-deep ring (no 128x128x32) */
@@ -53,7 +54,7 @@ extern "C" {
  * fp32 kernels ~1e-5 relative (inside the 1e-3 contract, not bit-comparable).  Takes the weights from
  * advhip_conv3d_pack_weight_bf16x3 instead of advhip_conv3d_pack_weight_f32.  Never chosen by ADVHIP_ALGO_AUTO. */
 #define ADVHIP_ALGO_BF16X3_BASE 128
-/* + tile id 1..4, 6..8: the LDS-DMA kernel with a 2-deep ring (one k-tile in flight): 16 KiB of LDS per 64x64x16
+/* + tile id 1..4, 6..9: the LDS-DMA kernel with a 2-deep ring (one k-tile in flight): 16 KiB of LDS per 64x64x16
  * workgroup instead of 24 -> 8 resident workgroups per CU instead of 6 */
 #define ADVHIP_ALGO_DMA2_BASE 160
 /* the 2-deep LDS-DMA kernel, 128x64x16 tile, with m-tiles that span T (2 or 4 frames x 64 / 32 flattened spatial positions)
@@ -531,7 +532,7 @@ int advhip_mil_magnitude_f32(const float* features, const float* scores, float* 
  * crop-major order (modeling_mgfn.py:349-355) and mean of the k selected scores (:359-362).
  *   mag, keep, sc : (n, T)         features : (n*ncrops, T, F)   [row = video*ncrops + crop]
  *   idx  : (n, k) int64            sel      : (ncrops*n, k, F)   [row = crop*n + video]
- *   score: (n)                     keep may be NULL (all ones).   T <= 4096, k <= 16. */
+ *   score: (n)                     keep may be NULL (all ones).   k <= min(16, T); T has no bound but int32 (n * T elements addressed as size_t). */
 int advhip_mil_topk_select_f32(const float* mag, const float* keep, const float* sc,
                                const float* features, int64_t* idx, float* sel, float* score,
                                int32_t n, int32_t ncrops, int32_t T, int32_t F, int32_t k,

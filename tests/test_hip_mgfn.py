@@ -117,6 +117,11 @@ def test_training_mode_draws_dropout_masks(model_and_sd):
 # ------------------------------------------------------------------ kernel-level (K9 / K10)
 @pytest.mark.parametrize("bs,ncrops,T,F,k,use_keep", [
     (4, 10, 32, 1024, 3, True), (2, 10, 57, 1024, 3, False), (6, 3, 200, 96, 5, True), (2, 1, 3, 7, 3, False),
+    # whole-video validation lengths (runner.py:42-50: T = n_clips): either side of the old 64 x 64-bit "taken" bitmap (4096),
+    # the 1- / 4- / 16-wave workgroups of mil_topk_kernel (T <= 2048 / <= 32768 / above)
+    (2, 2, 2048, 64, 3, True), (2, 2, 2049, 64, 3, False), (2, 2, 4096, 64, 3, True), (2, 2, 4096, 64, 3, False),
+    (2, 2, 4097, 64, 3, True), (2, 2, 4097, 64, 3, False), (2, 3, 10000, 32, 3, True), (2, 3, 10000, 32, 3, False),
+    (4, 1, 40000, 8, 16, True),
 ])
 def test_mil_magnitude_and_topk_select_fwd_bwd(bs, ncrops, T, F, k, use_keep):
     from anomaly_detection_on_video_amd import mil_ops

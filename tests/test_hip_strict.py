@@ -60,6 +60,14 @@ def scorer_and_sd():
     return m.to(DEV), sd
 
 
+def _long_video(T, crops=10, seed=0):
+    """mgfn_inputs' recipe -- |features| with a per-clip bump, true magnitude channel -- from torch's seeded CPU generator: the
+    hash generator needs ~7 s per 1000 clips, and both sides of these comparisons read the same tensor anyway."""
+    g = torch.Generator().manual_seed(1000 + T + seed)
+    feats = torch.rand((1, crops, T, 2048), generator=g) * 2.0 * (1.0 + torch.rand((1, 1, T, 1), generator=g))
+    return torch.cat([feats, torch.linalg.norm(feats, dim=3, keepdim=True)], dim=3)
+
+
 def test_strict_raises_where_a_layer_would_leave_the_kernels(strict):
     """The switch is live: a GlanceAttention with dim_head = 32 (outside the kernels' rules) raises under STRICT."""
     from anomaly_detection_on_video_amd import _lib
@@ -83,7 +91,9 @@ def test_eval_odd_T_reference_golden_under_strict(strict, scorer_and_sd):
     assert rel_err(o.abnormal_scores.cpu(), g["eval57_abn_scores"]) < TOL
 
 
-@pytest.mark.parametrize("T", [5, 57, 517, 32, 3])  # (T < k = 3: torch.topk raises in the reference too)
+# (T < k = 3: torch.topk raises in the reference too.  2048 / 4097 / 8192: videos of 9 to 36 minutes at 30 fps -- past the 4096-clip
+# limit the top-k kernel used to have; the attention, ring, GEMM and head kernels at ten-thousands of positions per crop)
+@pytest.mark.parametrize("T", [5, 57, 517, 32, 3, 2048, 4097, 8192])
 def test_validation_pass_any_T_vs_oracle_under_strict(strict, scorer_and_sd, T):
     """runner.validation_step's forward -- (1, 10, T, 2049), eval, no split -- for short, odd and long videos against the CPU
     oracle, every layer on the HIP kernels, and nothing but plumbing dispatched to ATen."""
@@ -93,7 +103,7 @@ def test_validation_pass_any_T_vs_oracle_under_strict(strict, scorer_and_sd, T):
     model.load_state_dict(sd)
     model.eval()
     model.force_split = False
-    video = mgfn_inputs(1, T, 11 + T)
+    video = mgfn_inputs(1, T, 11 + T) if T < 1024 else _long_video(T)
     with torch.no_grad():
         model(video=video.to(DEV))  # (lazily built operands: tables, packed / folded weights)
         with AtenAudit() as audit:
@@ -217,4 +227,45 @@ def test_variable_length_stream_soak_ring_wraps_under_lanes(strict):
         for (v, s), n in zip(scored, clips):
             want = ref_stream._score_eager(rows[s0 : s0 + n * crops].view(n, crops, -1))
             assert s.shape == (n,) and torch.isfinite(s).all() and torch.equal(s, want), v
+            s0 += n * crops
+
+
+def test_stream_scores_a_5000_clip_video_under_strict(strict):
+    """One untrimmed video of 5 000 clips x 10 crops (46 minutes at 30 fps) between two short ones on the three lanes: the ring is
+    50 048 rows + a 50 000-row mirror, the scoring pass runs at T = 5 000 (past the 4 096 clips mil_topk_select used to stop at).  Its
+    scores equal the scorer run directly on the gathered rows bit for bit, and the CPU oracle's MGFN on those rows within 1e-3."""
+    from anomaly_detection_on_video_amd.i3d import I3Res50
+    from anomaly_detection_on_video_amd.models.mgfn import MGFNConfig, MGFNForVideoAnomalyDetection
+    from anomaly_detection_on_video_amd.pipeline import ExtractScoreStream
+    from oracle import host_oracle, mgfn_oracle
+
+    bb = I3Res50()
+    bb.load_state_dict(synth_i3d_state_dict())
+    bb = bb.eval().to(DEV)
+    sc = MGFNForVideoAnomalyDetection(MGFNConfig())
+    msd = synth_module_state_dict(sc)
+    sc.load_state_dict(msd)
+    sc = sc.eval().to(DEV)
+    clips, crops, lb = [4, 5000, 6], 10, 32
+    stream = ExtractScoreStream(bb, sc, clips_per_video=clips, ncrops=crops, local_batch=lb)
+    assert stream.ring_rows == 50048 and stream.max_video_rows == 50000
+    steps = -(-sum(clips) * crops // lb)
+    base = synth_tensor("long.x", (48, 3, 16, 32, 32), scale=2.0).to(DEV)
+    handles = []
+    for k in range(steps):
+        idx = torch.tensor([((k * lb + j) * 7 + (k * lb + j) // 48) % 48 for j in range(lb)], device=DEV)
+        handles.append(stream.step_async(base[idx]))
+    stream.drain()
+    torch.cuda.synchronize()
+    rows = torch.cat([h.result()[0] for h in handles])
+    scored = [vs for h in handles for vs in h.result()[1]]
+    assert [v for v, _ in scored] == [0, 1, 2] and stream.scored_log == [(0, 4), (1, 5000), (2, 6)]
+    s0 = 0
+    with torch.no_grad():
+        for (v, s), n in zip(scored, clips):
+            f = rows[s0 : s0 + n * crops].view(n, crops, -1)
+            assert s.shape == (n,) and torch.equal(s, stream._score_eager(f)), v
+            if n == 5000:
+                video = torch.from_numpy(host_oracle.add_magnitude(f.cpu().numpy())).unsqueeze(0).permute(0, 2, 1, 3)
+                assert rel_err(s.cpu(), mgfn_oracle.mgfn_forward(video, msd).scores.reshape(-1)) < TOL
             s0 += n * crops

@@ -37,6 +37,8 @@ def main():
                                                   "anomaly_detection_on_video_amd", "tuned", "gfx950.json"))
     ap.add_argument("--report", default="")
     ap.add_argument("--quick", action="store_true", help="skip the generic-gather variants")
+    ap.add_argument("--algos", default="", help="comma-separated algo ids: time only these (e.g. 162,169 for a tile A/B)")
+    ap.add_argument("--max-splits", type=int, default=16)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     os.environ["ADV_NO_TUNED"] = "1"
@@ -68,12 +70,17 @@ def main():
             kpad = pc.w_packed.shape[0]
             cands = []
             taps = pc.kernel[0] * pc.kernel[1] * pc.kernel[2]
-            for algo in ((3,) if args.quick else _lib.IGEMM_ALGOS) + ((35,) if args.quick else _lib.FAST_ALGOS) + _lib.DMA_ALGOS + _lib.DMA4_ALGOS + _lib.DMA2_ALGOS:
+            pool = ((3,) if args.quick else _lib.IGEMM_ALGOS) + ((35,) if args.quick else _lib.FAST_ALGOS) + _lib.DMA_ALGOS + _lib.DMA4_ALGOS + _lib.DMA2_ALGOS
+            if args.algos:
+                pool = tuple(int(a) for a in args.algos.split(","))
+            for algo in pool:
                 bm, bn, bk = _lib.algo_tile(algo)
                 if pc.cout % bn:
                     continue
                 tiles = -(-(y.numel() // pc.cout) // bm) * (pc.cout // bn)
                 for sp in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16):
+                    if sp > args.max_splits:
+                        continue
                     if sp > 1 and (tiles * sp > 4096 or kpad // bk < 2 * sp):
                         continue
                     cands.append((algo, sp))
