@@ -38,13 +38,14 @@ BF16X3_ALGOS = tuple(ALGO_BF16X3_BASE + a for a in (5, 6))
 ALGO_DMA2_BASE = 160  # + tile id: LDS-DMA kernel, 2-deep ring (less LDS, more resident workgroups)
 DMA2_ALGOS = tuple(ALGO_DMA2_BASE + a for a in (1, 2, 3, 4, 6, 7, 8, 9))
 ALGO_TSPAN_128x64 = 192  # (kt,1,1) convs: 128x64 tile of 2 or 4 frames x flattened spatial positions
+ALGO_MIXED_128x64 = 200  # unsplit 1x1x1 stride-1 convs: 128x64 tiles + 64x64 tiles for the last, partial round of workgroups
 ALGO_PERSIST_BASE = 224  # + tile id (2: 128x64, 3: 64x64) + 8 * (workgroups per CU - 1), 1..3: persistent wave-specialised kernel (opt-in), unsplit 1x1x1 stride-1 convs, K >= 64
 PERSIST_ALGOS = tuple(ALGO_PERSIST_BASE + t + 8 * (w - 1) for w in (1, 2, 3) for t in (2, 3))
 
 
 def algo_tile(algo: int):
     """(BM, BN, BK) of an implicit-GEMM algorithm id."""
-    if algo == ALGO_TSPAN_128x64:
+    if algo in (ALGO_TSPAN_128x64, ALGO_MIXED_128x64):
         return (128, 64, 16)
     if ALGO_PERSIST_BASE <= algo < ALGO_PERSIST_BASE + 32:
         return (128 if (algo - ALGO_PERSIST_BASE) & 7 == 2 else 64, 64, 16)

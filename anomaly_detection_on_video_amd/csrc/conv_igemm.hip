@@ -105,6 +105,7 @@ struct ConvArgs {
   const float* ln_u;
   const float* ln_mu;
   const float* ln_rs;
+  int mix_big, mix_small, mix_mbase;  // conv1x1_mixed_tail_kernel: 128-row items, 64-row items, first row of the 64-row tiles
   int splits;         // 1 = fused epilogue; >1 = K cut into that many slices
   long long slab;     // elements per split-K slab (two-launch form: raw partial sums in y, reduced by splitk_reduce_kernel)
   // in-kernel reduction (LDS-DMA kernels): every (tile, slice) workgroup publishes its partial tile, draws a ticket on the
@@ -1225,19 +1226,26 @@ __device__ __forceinline__ void avg_epilogue(const ConvArgs& a, f32x4 (&acc)[BM 
   else avg_epilogue_body<BM, BN, BK, false>(a, acc, smem, b, n0, wave, lane, tid);
 }
 
+// LDS floats of one workgroup of the LDS-DMA kernel: the ring, reused as the epilogue's staging / brick area
+template <int BM, int BN, int BK, int NS, int EPI>
+constexpr int dma_smem_floats() {
+  using Cfg = IgemmCfg<BM, BN, BK>;
+  constexpr int RING = NS * DmaCfg<BM, BN, BK>::STAGE;
+  constexpr int BRICK_FLOATS = EPI == EPI_STD ? 0 : (EPI == EPI_AVG ? Cfg::ST_FLOATS + 2 * BN : (BN / Cfg::FN) * (BM + 4));  // one fragment column of every wave: [BN/FN channels][BM + 4]
+  constexpr int SMEM0 = RING > Cfg::ST_FLOATS ? RING : Cfg::ST_FLOATS;
+  return SMEM0 > BRICK_FLOATS ? SMEM0 : BRICK_FLOATS;
+}
+
+// The body of the kernel: work item `item` of `nitems` (tile, K-slice) items whose m-tiles start at row `m_base` of the M index
+// space.  conv3d_igemm_dma_kernel runs it on (blockIdx.x, the whole grid, 0); conv1x1_mixed_tail_kernel on two tile heights.
 template <int BM, int BN, int BK, bool CHECK, int NS = 3, int EPI = EPI_STD, bool U8 = false, int AMODE = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dma_waves_per_simd<BM, BN, BK, NS>(), 8)))
-void conv3d_igemm_dma_kernel(const ConvArgs a) {
+__device__ __forceinline__ void conv3d_igemm_dma_tile(const ConvArgs& a, float* smem, const int item, const int nitems, const int m_base) {
   using Cfg = IgemmCfg<BM, BN, BK>;
   using D = DmaCfg<BM, BN, BK>;
   constexpr int FM = Cfg::FM, FN = Cfg::FN, KR = D::KR, LA = D::LA, LB = D::LB, KS = BK / 4;
   static_assert(NS == 2 || NS == 3 || NS == 4, "ring depth");
   static_assert(LB >= 1 && LA >= 1 && (NS - 2) * (LA + LB) <= 63, "tile / vmcnt budget");
   constexpr unsigned OOB = 0xFFFFFF00u;
-  constexpr int RING = NS * D::STAGE;
-  constexpr int BRICK_FLOATS = EPI == EPI_STD ? 0 : (EPI == EPI_AVG ? Cfg::ST_FLOATS + 2 * BN : (BN / Cfg::FN) * (BM + 4));  // one fragment column of every wave: [BN/FN channels][BM + 4]
-  constexpr int SMEM0 = RING > Cfg::ST_FLOATS ? RING : Cfg::ST_FLOATS;
-  constexpr int SMEM = SMEM0 > BRICK_FLOATS ? SMEM0 : BRICK_FLOATS;
   static_assert(EPI == EPI_STD || (BM == 128 && BN == 64), "pooling epilogues: 128 x 64 tile (wave row = one t plane of the brick)");
   static_assert(EPI != EPI_AVG || (!CHECK && NS == 2 && !U8 && (AMODE == 0 || AMODE == 2)), "the mean epilogue: 1x1x1 convs on the 2-deep ring");
   static_assert(!U8 || (EPI == EPI_POOL233 && CHECK), "uint8 frame input: the stem + maxpool1 form (an m-tile lies in one crop)");
@@ -1248,14 +1256,10 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   static_assert(!A16ONLY || (!CHECK && NS == 2 && !U8 && epi_rows(EPI)), "compile-time a16: unchecked 1x1x1 convs on the 2-deep ring");
   constexpr int BRICK_T = brick_t(EPI), BRICK_H = EPI == EPI_POOL233 ? 4 : 1, BRICK_W = BM / (BRICK_T * BRICK_H);
 
-  __shared__ __attribute__((aligned(16))) float smem[SMEM];
-
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ntiles = a.tiles_m * a.tiles_n;
-  const int nitems = ntiles * a.splits;
-  const int item = (int)blockIdx.x;  // one (tile, K-slice) work item per workgroup (persistent grids measured slower)
+  // one (tile, K-slice) work item per workgroup (persistent grids measured slower)
   int L, split;
   // each XCD works on a contiguous range of (tile, K-slice) items: the K-slices of a tile and the n-tiles of an
   // m-tile (which re-read the same activation rows) meet in one L2
@@ -1268,7 +1272,7 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
     L = it;
   }
   const int tile_m = (int)a.dTilesN.div((unsigned)L), tile_n = L - tile_m * a.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = m_base + tile_m * BM, n0 = tile_n * BN;
 
   const int ml = tid % BM;
   const int kr = __builtin_amdgcn_readfirstlane(tid / BM);
@@ -1668,6 +1672,29 @@ void conv3d_igemm_dma_kernel(const ConvArgs a) {
   }
   // (one epilogue call site: a second inlined copy costs ~25 VGPRs and with them a resident workgroup per CU)
   igemm_epilogue<BM, BN, BK>(a, acc, smem, 0, m0, n0, wave, lane, true);
+}
+
+template <int BM, int BN, int BK, bool CHECK, int NS = 3, int EPI = EPI_STD, bool U8 = false, int AMODE = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dma_waves_per_simd<BM, BN, BK, NS>(), 8)))
+void conv3d_igemm_dma_kernel(const ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[dma_smem_floats<BM, BN, BK, NS, EPI>()];
+  conv3d_igemm_dma_tile<BM, BN, BK, CHECK, NS, EPI, U8, AMODE>(a, smem, (int)blockIdx.x, a.tiles_m * a.tiles_n * a.splits, 0);
+}
+
+// ---- one launch, two tile heights: the tail of a launch that is just over a whole number of rounds -------------------------------
+// An unsplit 1x1x1 stride-1 conv on 16-byte aligned rows (the `conv3` + residual launches, src/i3d.py:85-89, 108-121) whose 128 x 64
+// tiles number a little more than the resident slots (layer3.x.conv3 at B = 32: 98 x 16 = 1 568 tiles on 256 CUs x 6 = 1 536) pays a
+// second round in which 32 workgroups run alone (profiles/r05_tile_tail.txt: 62.2 us against 54.6 at exactly one round).  Here the last
+// m-tile rows of the launch are cut into 64-row tiles, enough of them that every workgroup of the second round is a 64 x 64 one -- half
+// the MFMA chain per k-tile, so the tail is about half as long.  Items [0, mix_big) are 128 x 64 tiles, the rest 64 x 64 tiles from row
+// mix_mbase on; both bodies are the ones of conv3d_igemm_dma_kernel (same K order and accumulation per output: the same bits).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dma_waves_per_simd<128, 64, 16, 2>(), 8)))
+void conv1x1_mixed_tail_kernel(const ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[dma_smem_floats<128, 64, 16, 2, EPI_STD>()];
+  static_assert(dma_smem_floats<128, 64, 16, 2, EPI_STD>() >= dma_smem_floats<64, 64, 16, 2, EPI_STD>(), "the tall tile's LDS holds the short one's");
+  const int bid = (int)blockIdx.x;
+  if (bid < a.mix_big) conv3d_igemm_dma_tile<128, 64, 16, false, 2, EPI_STD, false, 2>(a, smem, bid, a.mix_big, 0);
+  else conv3d_igemm_dma_tile<64, 64, 16, false, 2, EPI_STD, false, 2>(a, smem, bid - a.mix_big, a.mix_small, a.mix_mbase);
 }
 
 // ================================================================================================
@@ -2908,7 +2935,7 @@ static int persist_tile(int algo) { return (algo - ADVHIP_ALGO_PERSIST_BASE) & 7
 static int persist_wgs_per_cu(int algo) { return ((algo - ADVHIP_ALGO_PERSIST_BASE) >> 3) + 1; }
 
 static void tile_of(int algo, int* BM, int* BN, int* BK) {
-  if (algo == ADVHIP_ALGO_TSPAN_128x64) { *BM = 128; *BN = 64; *BK = 16; return; }
+  if (algo == ADVHIP_ALGO_TSPAN_128x64 || algo == ADVHIP_ALGO_MIXED_128x64) { *BM = 128; *BN = 64; *BK = 16; return; }
   if (is_persist(algo)) { *BM = persist_tile(algo) == ADVHIP_ALGO_IGEMM_128x64 ? 128 : 64; *BN = 64; *BK = 16; return; }
   if (algo == ADVHIP_ALGO_DMA2_BASE + ADVHIP_ALGO_IGEMM_256x64) { *BM = 256; *BN = 64; *BK = 16; return; }
   if (algo >= ADVHIP_ALGO_DMA2_BASE) algo -= ADVHIP_ALGO_DMA2_BASE;
@@ -2925,7 +2952,7 @@ static void tile_of(int algo, int* BM, int* BN, int* BK) {
 // Which (family, tile) ids have a kernel in this library.  Ids inside a family's range without an instantiation
 // (e.g. DMA_BASE + 5) are rejected up front: a launch switch that fell through would return OK with y unwritten.
 static bool instantiated(int algo) {
-  if (algo == ADVHIP_ALGO_TSPAN_128x64) return true;
+  if (algo == ADVHIP_ALGO_TSPAN_128x64 || algo == ADVHIP_ALGO_MIXED_128x64) return true;
   if (algo >= ADVHIP_ALGO_PERSIST_BASE) return is_persist(algo) && (persist_tile(algo) == ADVHIP_ALGO_IGEMM_128x64 || persist_tile(algo) == ADVHIP_ALGO_IGEMM_64x64) && persist_wgs_per_cu(algo) <= 3;
   auto tile_in = [](int t, unsigned mask) { return t >= 1 && t <= 8 && ((mask >> t) & 1u); };
   constexpr unsigned ALL = 0x1FEu, NO5 = ALL & ~(1u << 5);
@@ -3163,6 +3190,7 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
   const int nk = (g.Kpad + BK - 1) / BK;
   ADVHIP_REQUIRE(c.splits >= 1 && c.splits <= nk && c.splits <= 64, "conv3d: bad split count %d (k-tiles %d)", c.splits, nk);
   a.part = nullptr; a.cnt = nullptr; a.part_bytes = 0;
+  a.mix_big = a.mix_small = a.mix_mbase = 0;
   const SplitLayout lay = split_layout(d, g, c);
   if (c.splits > 1) {
     ADVHIP_REQUIRE(workspace != nullptr && workspace_bytes >= lay.total(),
@@ -3187,7 +3215,7 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
   long long Mv = M;
   bool a16pad = false;
   if (nocheck && d->st == 1 && d->sh == 1 && d->sw == 1 && a.THW % 4 != 0 && ((uintptr_t)x & 15) == 0 && c.splits == 1 &&
-      ((c.algo > ADVHIP_ALGO_DMA2_BASE && c.algo <= ADVHIP_ALGO_DMA2_BASE + ADVHIP_ALGO_IGEMM_256x64) || is_persist(c.algo)) && !ln && y_preact == nullptr && dact_z == nullptr) {
+      ((c.algo > ADVHIP_ALGO_DMA2_BASE && c.algo <= ADVHIP_ALGO_DMA2_BASE + ADVHIP_ALGO_IGEMM_256x64) || c.algo == ADVHIP_ALGO_MIXED_128x64 || is_persist(c.algo)) && !ln && y_preact == nullptr && dact_z == nullptr) {
     a.MP = (a.THWo + 3) / 4 * 4;
     Mv = (long long)d->B * a.MP;
     if (Mv < (1ll << 31)) {
@@ -3281,6 +3309,28 @@ extern "C" int advhip_conv3d_bn_act_ex_f32(const advhip_conv3d_desc* d, const fl
     // (a.a16 is always set here -- the rows are padded in the M index space -- so the compile-time a16 form applies)
     hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, false, 2, EPI_AVG, false, 2>), grid, dim3(256), 0, st, a);
     return check_launch("conv3d + mean");
+  }
+  if (c.algo == ADVHIP_ALGO_MIXED_128x64) {
+    ADVHIP_REQUIRE(a.a16 != 0 && c.splits == 1 && !ln && dact_z == nullptr && y_preact == nullptr,
+                   "conv3d: ADVHIP_ALGO_MIXED_128x64 takes unsplit 1x1x1 stride-1 convs on 16-byte aligned rows without the MGFN epilogue operands "
+                   "(k=%d,%d,%d, splits=%d)", d->kt, d->kh, d->kw, c.splits);
+    // 128-row m-tiles, and how many of the last ones to cut into 64-row tiles: all the workgroups past the last whole round of
+    // resident slots (6 per CU) must be short ones -- cutting `c` tall m-tile rows adds c * tiles_n workgroups, so c >= rem / tiles_n.
+    // A launch that is below one round, on a round boundary or far into a round is the plain 128 x 64 launch.
+    const long long mt = (Mv + 127) / 128, tn = a.tiles_n, slots = 6ll * device_cus();
+    const long long rem = (mt * tn) % slots;
+    long long cut = (mt * tn > slots && rem > 0 && rem * 4 <= slots) ? (rem + tn - 1) / tn : 0;
+    if (cut > mt) cut = mt;
+    if (cut == 0) {
+      hipLaunchKernelGGL((conv3d_igemm_dma_kernel<128, 64, 16, false, 2, EPI_STD, false, 2>), grid, dim3(256), 0, st, a);
+      return check_launch("conv3d mixed (plain)");
+    }
+    const long long big_rows = (mt - cut) * 128, small_mt = (Mv - big_rows + 63) / 64;
+    a.mix_big = (int)((mt - cut) * tn);
+    a.mix_small = (int)(small_mt * tn);
+    a.mix_mbase = (int)big_rows;
+    hipLaunchKernelGGL(conv1x1_mixed_tail_kernel, dim3((unsigned)(a.mix_big + a.mix_small)), dim3(256), 0, st, a);
+    return check_launch("conv3d mixed tail");
   }
   if (is_persist(c.algo)) {
     // workgroups that stay: `wgs_per_cu` per compute unit (a multiple of 8 in all, at most one per tile), each walking its share of the tiles

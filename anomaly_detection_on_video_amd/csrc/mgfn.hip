@@ -1346,6 +1346,143 @@ __global__ __launch_bounds__(256) void glance_attn_fwd_anyt_kernel(const float* 
     if (i_base + i0 + e < T) out[(row0 + d2) * N + col0 + i_base + i0 + e] = o[e] / l_s[i0 + e];
 }
 
+// ---- the same forward on the matrix pipe (v_mfma_f32_16x16x4_f32, exact fp32 products) for whole-video lengths -----------------
+// A validation pass scores a video with T = its clip count (runner.py:42-50): at T in the thousands the T x T products are the
+// only part of GlanceAttention that grows quadratically (10 crops x 8192^2 x 64 x 4 FLOP = 172 GFLOP at T = 8192).  One workgroup
+// per (64-query tile, sequence, head), four waves of 16 queries each; key / value tiles of 64 clips.  Everything is computed
+// TRANSPOSED so that no operand ever changes lanes:
+//   S^T[key][query] = sum_d K[d][key] Q[d][query]      A = K^T from LDS (kt[key][d]: one ds_read_b128 = the operands of 4 k-steps),
+//                                                       B = this wave's Q columns, 16 registers loaded once
+//   O^T[d][query]  += sum_key V[d][key] P^T[key][query] A = V from LDS (vs[d][key], b128 as above), B = P^T = exp(S^T - m) AS IT SITS in
+//                                                       the accumulators of the first product (a contraction index may be permuted
+//                                                       as long as A and B agree: k-step (jk, e) of lane group lg is key 16 jk + 4 lg + e
+//                                                       on both sides)
+// A query is a COLUMN (lane & 15): its running maximum / sum need the 16 values of a lane and two xor-shuffles (lanes 16 / 32 apart).
+// The next tile's K / V rows are fetched into registers while the current tile is multiplied.  Same recurrence, masks and lse as
+// glance_attn_fwd_anyt_kernel; the summation order inside a dot product differs (MFMA chains of 4), so the two agree to rounding.
+constexpr int GM_Q = 64, GM_K = 64, GM_KP = GA_D + 4, GM_VP = GM_K + 4;  // LDS pitches: 272-byte rows -> conflict-free b128 fragment reads
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void glance_attn_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ lse,
+                                                                   int inner, int heads, int T, long long N, float scale, int bh0) {
+  __shared__ __attribute__((aligned(16))) float kt[GM_K][GM_KP];  // kt[key][d]
+  __shared__ __attribute__((aligned(16))) float vs[GA_D][GM_VP];  // vs[d][key]
+  const int bh = bh0 + blockIdx.y, b = bh / heads, h = bh % heads, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const long long col0 = (long long)b * T, row0 = (long long)h * GA_D;
+  const float* __restrict__ qp = qkv + row0 * N + col0;
+  const float* __restrict__ kp = qkv + ((long long)inner + row0) * N + col0;
+  const float* __restrict__ vp = qkv + (2ll * inner + row0) * N + col0;
+  const int qi = blockIdx.x * GM_Q + wave * 16 + li;  // this lane's query (a column of every fragment)
+  const bool q_ok = qi < T;
+  // B operand of the first product: qreg[c][e] = Q[d = 16 c + 4 lg + e][qi]
+  float qreg[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) qreg[c][e] = q_ok ? qp[(long long)(16 * c + 4 * lg + e) * N + qi] : 0.f;
+  // staging map of the K / V tiles: thread = key `lane`, d group `wave`: K rows d = 16 i + 4 wave + e (b128 LDS writes kt[key][d .. d+3]),
+  // V rows d = 16 i + 4 wave + e as well (dword LDS writes vs[d][key]); global reads run along the keys: 256 contiguous bytes per wave
+  float kst[4][4], vst[4][4];
+  const int wrow = __builtin_amdgcn_readfirstlane(4 * wave);
+  const float* __restrict__ kpl = kp + (long long)wrow * N + lane;  // this thread's column of the wave's first row; the rest is wave-uniform
+  const float* __restrict__ vpl = vp + (long long)wrow * N + lane;
+  auto fetch = [&](int jb) __attribute__((always_inline)) {
+    if (jb + lane < T) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const long long o = (long long)(16 * i + e) * N + jb;
+          kst[i][e] = kpl[o];
+          vst[i][e] = vpl[o];
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) kst[i][e] = vst[i][e] = 0.f;
+    }
+  };
+  auto stash = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float4*>(&kt[lane][16 * i + 4 * wave]) = make_float4(kst[i][0], kst[i][1], kst[i][2], kst[i][3]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vs[16 * i + 4 * wave + e][lane] = vst[i][e];
+    }
+  };
+  f32x4 o[4];  // O^T fragment jd: rows d = 16 jd + 4 lg + r, column qi
+#pragma unroll
+  for (int jd = 0; jd < 4; ++jd) o[jd] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = GA_NEG, l = 0.f;
+  fetch(0);
+  for (int jb = 0; jb < T; jb += GM_K) {
+    __syncthreads();  // the previous tile's fragment reads are done
+    stash();
+    __syncthreads();
+    if (jb + GM_K < T) fetch(jb + GM_K);  // in flight under this tile's products
+    f32x4 s[4];  // S^T fragment jk: rows key = jb + 16 jk + 4 lg + r, column qi
+#pragma unroll
+    for (int jk = 0; jk < 4; ++jk) s[jk] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (consecutive MFMAs go to DIFFERENT accumulators: four independent chains keep the pipe issuing back to back)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f32x4 a[4];
+#pragma unroll
+      for (int jk = 0; jk < 4; ++jk) a[jk] = *reinterpret_cast<const f32x4*>(&kt[16 * jk + li][16 * c + 4 * lg]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int jk = 0; jk < 4; ++jk) s[jk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jk][e], qreg[c][e], s[jk], 0, 0, 0);
+    }
+    float mx = GA_NEG;
+#pragma unroll
+    for (int jk = 0; jk < 4; ++jk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = (jb + 16 * jk + 4 * lg + r < T) ? s[jk][r] * scale : GA_NEG;
+        s[jk][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx);  // (finite from the first tile on: key jb is always a real one)
+    const float alpha = expf(m - m_new);
+    float sum = 0.f;
+#pragma unroll
+    for (int jk = 0; jk < 4; ++jk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = (jb + 16 * jk + 4 * lg + r < T) ? expf(s[jk][r] - m_new) : 0.f;
+        s[jk][r] = pv;
+        sum += pv;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    l = l * alpha + sum;
+    m = m_new;
+#pragma unroll
+    for (int jd = 0; jd < 4; ++jd) o[jd] *= alpha;
+#pragma unroll
+    for (int jk = 0; jk < 4; ++jk) {
+      f32x4 a[4];
+#pragma unroll
+      for (int jd = 0; jd < 4; ++jd) a[jd] = *reinterpret_cast<const f32x4*>(&vs[16 * jd + li][16 * jk + 4 * lg]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int jd = 0; jd < 4; ++jd) o[jd] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jd][e], s[jk][e], o[jd], 0, 0, 0);
+    }
+  }
+  if (!q_ok) return;
+  const float inv = 1.f / l;
+  float* __restrict__ op = out + row0 * N + col0 + qi;
+#pragma unroll
+  for (int jd = 0; jd < 4; ++jd)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) op[(long long)(16 * jd + 4 * lg + r) * N] = o[jd][r] * inv;
+  if (lse != nullptr && lg == 0) lse[(long long)bh * T + qi] = m + logf(l);
+}
+
 // backward for any T from dout, qkv, out and lse: p[i][j] = exp(scale q_i.k_j - lse[i]) is recomputed tile by tile;
 //   D[i] = sum_d dout[d][i] out[d][i];  dp = dout^T v;  ds = p (dp - D) scale;
 //   blockIdx.z = 0: dq[d][i] = sum_j ds[i][j] k[d][j] for one query tile (loop over the key tiles);
@@ -1730,16 +1867,25 @@ extern "C" int advhip_glance_attention_bwd_f32(const float* dout, const float* q
   return check_launch("glance_attention_bwd");
 }
 
+constexpr int GLANCE_MFMA_MIN_T = 256;
 extern "C" int advhip_glance_attention_fwd_anyt_f32(const float* qkv, float* out, float* lse, int32_t heads, int64_t B, int32_t T, int32_t dim_head,
                                                     float scale, void* stream) {
   ADVHIP_REQUIRE(qkv && out && heads > 0 && B > 0 && T > 0, "glance_attention_fwd_anyt: bad arguments");
   ADVHIP_REQUIRE(dim_head == GA_D, "glance_attention_anyt: dim_head = %d (the kernel is built for %d)", dim_head, GA_D);
   ADVHIP_REQUIRE(B * heads < (1ll << 31), "glance_attention_anyt: too many (sequence, head) pairs");
-  const unsigned tiles = (unsigned)((T + GA_T - 1) / GA_T);
+  // the matrix-pipe form from GLANCE_MFMA_MIN_T clips on (below it a pass is a few dozen workgroups of a handful of key tiles: the
+  // 32-query tiles of the vector kernel give the chip more of them); ADVHIP_GLANCE_MFMA_MIN_T in the environment moves the switch
+  static const int mfma_min_t = [] { const char* e = getenv("ADVHIP_GLANCE_MFMA_MIN_T"); return e ? atoi(e) : GLANCE_MFMA_MIN_T; }();
+  const bool mfma = T >= mfma_min_t;
+  const unsigned tiles = mfma ? (unsigned)((T + GM_Q - 1) / GM_Q) : (unsigned)((T + GA_T - 1) / GA_T);
   for (long long bh0 = 0; bh0 < B * heads; bh0 += 32768) {  // (grid.y is 16 bits wide)
     const unsigned ny = (unsigned)std::min<long long>(32768, B * heads - bh0);
-    hipLaunchKernelGGL(glance_attn_fwd_anyt_kernel, dim3(tiles, ny), dim3(256), 0, (hipStream_t)stream, qkv, out, lse, heads * GA_D, heads, T,
-                       (long long)B * T, scale, (int)bh0);
+    if (mfma)
+      hipLaunchKernelGGL(glance_attn_fwd_mfma_kernel, dim3(tiles, ny), dim3(256), 0, (hipStream_t)stream, qkv, out, lse, heads * GA_D, heads, T,
+                         (long long)B * T, scale, (int)bh0);
+    else
+      hipLaunchKernelGGL(glance_attn_fwd_anyt_kernel, dim3(tiles, ny), dim3(256), 0, (hipStream_t)stream, qkv, out, lse, heads * GA_D, heads, T,
+                         (long long)B * T, scale, (int)bh0);
   }
   return check_launch("glance_attention_fwd_anyt");
 }

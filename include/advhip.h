@@ -61,6 +61,11 @@ extern "C" {
  * for (kt,1,1) stride-1 "same" convs: the temporal taps of a tile re-read the same activation rows from L1/L2 instead of
  * three far-apart tiles fetching them from HBM.  Unsplit; T even. */
 #define ADVHIP_ALGO_TSPAN_128x64 192
+/* the 2-deep LDS-DMA kernel for unsplit 1x1x1 stride-1 convs on 16-byte aligned rows, 128x64x16 tiles, with the last m-tile rows cut
+ * into 64x64 tiles when the 128x64 tiles number a little more than a whole number of rounds of resident workgroups (6 per compute
+ * unit): every workgroup of the last, partial round is then a short one.  Same K order per output as the plain tiles: bit-identical
+ * results.  Launches below one round / on a round boundary are the plain 128x64 launch. */
+#define ADVHIP_ALGO_MIXED_128x64 200
 /* + tile id (ADVHIP_ALGO_IGEMM_128x64 or _64x64) + 8 * (W - 1), W = 1..3 workgroups per compute unit: a PERSISTENT, wave-specialised
  * kernel for unsplit 1x1x1 stride-1 convs on 16-byte aligned rows with K >= 64 (the `conv3` + residual launches,
  * src/i3d.py:85-89, 108-121): eight-wave workgroups that stay for the whole launch and walk a share of the output tiles; four waves

@@ -101,7 +101,7 @@ def test_uninstantiated_algo_ids_are_rejected_without_gpu():
     from anomaly_detection_on_video_amd import _lib
 
     lib = _lib.load()
-    ok = set([0, _lib.ALGO_TSPAN_128x64]) | set(_lib.IGEMM_ALGOS) | set(_lib.FAST_ALGOS) | set(_lib.DMA_ALGOS) | set(_lib.DMA4_ALGOS) | set(_lib.BF16X3_ALGOS) | set(_lib.DMA2_ALGOS) | set(_lib.PERSIST_ALGOS)
+    ok = set([0, _lib.ALGO_TSPAN_128x64, _lib.ALGO_MIXED_128x64]) | set(_lib.IGEMM_ALGOS) | set(_lib.FAST_ALGOS) | set(_lib.DMA_ALGOS) | set(_lib.DMA4_ALGOS) | set(_lib.BF16X3_ALGOS) | set(_lib.DMA2_ALGOS) | set(_lib.PERSIST_ALGOS)
     for algo in range(0, 300):
         d = _lib.ConvDesc(2, 64, 4, 13, 11, 128, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1, algo, 1)
         rc = lib.advhip_conv3d_workspace_bytes(C.byref(d))

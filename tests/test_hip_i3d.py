@@ -267,6 +267,55 @@ def test_conv_tspan_rejects_what_it_cannot_run():
         ops.conv3d_bn_act(x.to(dev), pc, algo=_lib.ALGO_TSPAN_128x64)
 
 
+MIXED_CASES = [  # (name, Cin, Cout, (B, T, H, W)): 1x1x1 convs whose 128 x 64 tiles number a little more than one round of 6 x 256 resident workgroups
+    ("mixed.even", 64, 128, (1, 1, 8, 12416)),    # M = 776 x 128: 1 552 tiles, 16 past the round -> the last 8 tall m-tile rows cut in two
+    ("mixed.ragged", 64, 128, (1, 1, 1, 98596)),  # M = 770 x 128 + 36: 1 542 tiles -> 3 rows cut; the last 64-row tile holds 36 positions
+    ("mixed.rows98", 64, 256, (494, 2, 7, 7)),    # 98 positions per sample (layer-4 planes): every sample's rows padded to 100 in the M index space
+    ("mixed.below", 64, 128, (1, 1, 4, 512)),     # below one round: the plain 128 x 64 launch
+]
+
+
+@pytest.mark.parametrize("case", MIXED_CASES, ids=[c[0] for c in MIXED_CASES])
+def test_conv_mixed_tail_equals_the_plain_tiles_bit_for_bit(case):
+    """ADVHIP_ALGO_MIXED_128x64: the last m-tile rows of an unsplit 1x1x1 conv as 64 x 64 tiles, so that the partial last round of
+    workgroups is short ones (conv1x1_mixed_tail_kernel).  Same K order per output as the plain 128 x 64 launch: the same bits, with
+    and without residual / ReLU; fp64 torch reference within 2e-5."""
+    from anomaly_detection_on_video_amd import _lib, ops
+
+    name, cin, cout, bthw = case
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(len(name))
+    x = torch.randn((bthw[0], cin) + tuple(bthw[1:]), device=dev, generator=g)
+    wt = torch.randn((cout, cin, 1, 1, 1), device=dev, generator=g) * (2.0 / cin) ** 0.5
+    gam, bet = torch.rand(cout, device=dev, generator=g) + 0.5, torch.randn(cout, device=dev, generator=g) * 0.2
+    mu, var = torch.randn(cout, device=dev, generator=g) * 0.2, torch.rand(cout, device=dev, generator=g) + 0.5
+    pc = ops.pack_conv(wt, gam, bet, mu, var, 1e-5, (1, 1, 1), (0, 0, 0), name=name)
+    res = torch.randn((bthw[0], cout) + tuple(bthw[1:]), device=dev, generator=g)
+    sc = (gam / torch.sqrt(var + 1e-5)).double()
+    ref0 = torch.einsum("oc,bcthw->bothw", wt.view(cout, cin).double(), x.double()) * sc.view(1, -1, 1, 1, 1) + (bet.double() - mu.double() * sc).view(1, -1, 1, 1, 1)
+    for use_res, relu in ((False, True), (True, True), (True, False)):
+        out = ops.conv3d_bn_act(x, pc, relu=relu, residual=res if use_res else None, algo=_lib.ALGO_MIXED_128x64, splits=1)
+        plain = ops.conv3d_bn_act(x, pc, relu=relu, residual=res if use_res else None, algo=162, splits=1)
+        assert torch.equal(out, plain), f"{name} res={use_res} relu={relu}"
+        ref = ref0 + res.double() if use_res else ref0
+        ref = ref.clamp_min(0) if relu else ref
+        assert rel_err(out.cpu(), ref.cpu()) < TIGHT
+    buf = res.clone()  # the residual may be the output buffer (Bottleneck.forward's `out += residual`, src/i3d.py:108-121)
+    ops.conv3d_bn_act(x, pc, relu=True, residual=buf, algo=_lib.ALGO_MIXED_128x64, splits=1, out=buf)
+    assert torch.equal(buf, ops.conv3d_bn_act(x, pc, relu=True, residual=res, algo=162, splits=1))
+
+
+def test_conv_mixed_tail_rejects_what_it_cannot_run():
+    from anomaly_detection_on_video_amd import _lib, ops
+
+    dev = _dev()
+    case = next(c for c in CONV_CASES if c[0] == "l1.conv2")  # a spatial window
+    x, wt, g, be, mu, var, _res = _conv_case(*case)
+    pc = ops.pack_conv(wt.to(dev), g.to(dev), be.to(dev), mu.to(dev), var.to(dev), 1e-5, case[4], case[5], name="l1.conv2")
+    with pytest.raises(_lib.HipExtensionError, match="MIXED"):
+        ops.conv3d_bn_act(x.to(dev), pc, algo=_lib.ALGO_MIXED_128x64, splits=1)
+
+
 @pytest.mark.parametrize("shape,k,s", [
     ((2, 64, 8, 28, 30), (2, 3, 3), (2, 2, 2)),   # maxpool1 (odd output extents)
     ((2, 256, 4, 11, 13), (2, 1, 1), (2, 1, 1)),  # maxpool2

@@ -379,7 +379,9 @@ def test_unfold3_is_bit_exact(shape):
     assert got.shape == ref.shape and torch.equal(got.cpu(), ref)
 
 
-@pytest.mark.parametrize("heads,b,t", [(1, 320, 32), (2, 7, 32), (3, 1, 32), (1, 10, 5), (1, 10, 57), (2, 3, 64), (1, 10, 517), (3, 2, 33), (1, 4, 1)])
+# (t >= 256: the forward on the matrix pipe, glance_attn_fwd_mfma_kernel -- 64-query / 64-key tiles, tails of 0, 1, 5, 63 clips)
+@pytest.mark.parametrize("heads,b,t", [(1, 320, 32), (2, 7, 32), (3, 1, 32), (1, 10, 5), (1, 10, 57), (2, 3, 64), (1, 10, 517), (3, 2, 33), (1, 4, 1),
+                                       (1, 2, 256), (2, 3, 257), (1, 10, 1151), (1, 1, 2048)])
 def test_glance_attention_core_fwd_bwd_vs_fp64_autograd(heads, b, t):
     """advhip_glance_attention_fwd/bwd[_anyt]_f32 (scale, q^T k, softmax over the keys, v attn^T and the "b h n d -> b (h d) n"
     layout of GlanceAttention, modeling_mgfn.py:113-122, on (C, B, T) activations) against the same formulas in fp64 autograd:
@@ -418,6 +420,20 @@ def test_glance_attention_anyt_handles_a_peaked_softmax():
     q, k, v = (u.permute(2, 0, 1, 3) for u in x.view(3, heads, dh, b, t).unbind(0))
     sim = torch.matmul((q * dh ** -0.5).transpose(-1, -2), k)
     ref = torch.matmul(v, sim.softmax(dim=-1).transpose(-1, -2)).permute(1, 2, 0, 3).reshape(dh, b, t)
+    assert torch.isfinite(out).all() and rel_err(out.cpu(), ref) < 1e-5
+
+
+def test_glance_attention_mfma_form_handles_a_peaked_softmax():
+    """The same stress on the matrix-pipe forward (T >= 256, two heads, six 64-key tiles with a 13-clip tail)."""
+    from anomaly_detection_on_video_amd import mgfn_ops
+
+    heads, b, t, dh = 2, 2, 333, 64
+    qkv = synth_tensor("ga.peak.mfma", (3 * heads * dh, b, t), scale=6.0).to(DEV)
+    out = mgfn_ops.glance_attention_core(qkv, heads, dh, dh ** -0.5)
+    x = qkv.double().cpu()
+    q, k, v = (u.permute(2, 0, 1, 3) for u in x.view(3, heads, dh, b, t).unbind(0))
+    sim = torch.matmul((q * dh ** -0.5).transpose(-1, -2), k)
+    ref = torch.matmul(v, sim.softmax(dim=-1).transpose(-1, -2)).permute(1, 2, 0, 3).reshape(heads * dh, b, t)
     assert torch.isfinite(out).all() and rel_err(out.cpu(), ref) < 1e-5
 
 

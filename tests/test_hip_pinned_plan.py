@@ -182,7 +182,7 @@ def test_uninstantiated_algo_ids_raise_on_device():
     one = torch.ones(128, device=dev)
     pc = ops.pack_conv(w, one, one * 0, one * 0, one, 1e-5, (1, 1, 1), (0, 0, 0), name="rej")
     x = synth_tensor("rej.x", (2, 64, 2, 5, 6)).to(dev)
-    for algo in (69, 97, 101, 102, 103, 104, 129, 130, 131, 132, 135, 136, 165, 9, 41, 73, 105, 137, 169):
+    for algo in (69, 97, 101, 102, 103, 104, 129, 130, 131, 132, 135, 136, 165, 9, 41, 73, 105, 137, 170, 199, 201):  # (169 = the 256 x 64 tile and 200 = the mixed-tail launch exist since round 6)
         with pytest.raises(_lib.HipExtensionError, match="not instantiated"):
             ops.conv3d_bn_act(x, pc, algo=algo)
     y = ops.conv3d_bn_act(x, pc, algo=67)
