@@ -1874,9 +1874,9 @@ extern "C" int advhip_glance_attention_fwd_anyt_f32(const float* qkv, float* out
   ADVHIP_REQUIRE(dim_head == GA_D, "glance_attention_anyt: dim_head = %d (the kernel is built for %d)", dim_head, GA_D);
   ADVHIP_REQUIRE(B * heads < (1ll << 31), "glance_attention_anyt: too many (sequence, head) pairs");
   // the matrix-pipe form from GLANCE_MFMA_MIN_T clips on (below it a pass is a few dozen workgroups of a handful of key tiles: the
-  // 32-query tiles of the vector kernel give the chip more of them); ADVHIP_GLANCE_MFMA_MIN_T in the environment moves the switch
-  static const int mfma_min_t = [] { const char* e = getenv("ADVHIP_GLANCE_MFMA_MIN_T"); return e ? atoi(e) : GLANCE_MFMA_MIN_T; }();
-  const bool mfma = T >= mfma_min_t;
+  // 32-query tiles of the vector kernel give the chip more of them).  A compile-time constant: the library reads no environment
+  // (the A/B of profiles/r06_studies.md section 4 was a study build)
+  const bool mfma = T >= GLANCE_MFMA_MIN_T;
   const unsigned tiles = mfma ? (unsigned)((T + GM_Q - 1) / GM_Q) : (unsigned)((T + GA_T - 1) / GA_T);
   for (long long bh0 = 0; bh0 < B * heads; bh0 += 32768) {  // (grid.y is 16 bits wide)
     const unsigned ny = (unsigned)std::min<long long>(32768, B * heads - bh0);

@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 6, GPU run b: MFMA attention tests + scoring-pass A/B, 256x64 tile PMC, layer-4 split-K in-stream A/B
+# (ADVHIP_GLANCE_MFMA_MIN_T: an environment switch of the STUDY build this script ran on; the committed library has the threshold as a constant)
 O=gpurun_out/r6b; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python -m pytest tests/test_hip_mgfn.py -m gpu -x -q -k "glance" > $O/tests_glance.log 2>&1; echo rc=$? >> $O/tests_glance.log; tail -3 $O/tests_glance.log
