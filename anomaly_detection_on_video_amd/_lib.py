@@ -171,6 +171,9 @@ SIGNATURES = {
     "advhip_dwconv_t_bwd_f32": (C.c_int, [_P] * 5 + [_I, _I, _L, _I, _I, _P]),
     "advhip_glance_attention_fwd_f32": (C.c_int, [_P, _P, _P, _I, _L, _I, _I, C.c_float, _P]),
     "advhip_glance_attention_bwd_f32": (C.c_int, [_P, _P, _P, _P, _I, _L, _I, _I, C.c_float, _P]),
+    "advhip_ffn_block_partial_rows": (_L, [_L]),
+    "advhip_ffn_block_fwd_f32": (C.c_int, [_P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _P]),
+    "advhip_ffn_block_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P, _I, _L, _P]),
     "advhip_glance_attention_fwd_anyt_f32": (C.c_int, [_P, _P, _P, _I, _L, _I, _I, C.c_float, _P]),
     "advhip_glance_attention_bwd_anyt_f32": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _I, _I, C.c_float, _P]),
     "advhip_fold_affine_f32": (C.c_int, [_P] * 7 + [_I, _I, _P]),

@@ -648,6 +648,20 @@ class _FFNBlockCN(torch.autograd.Function):
         mu = torch.empty((n,), device=x.device, dtype=torch.float32)
         rs = torch.empty_like(mu)
         gf, bf = g.detach().reshape(c).contiguous(), b.detach().reshape(c).contiguous()
+        ctx.fused = fused_ffn_ok(c, hid, n, w1, w2)
+        if ctx.fused:
+            # the narrow blocks (64 / 128 channels): LayerNorm, both GEMMs, GELU and the residual add as ONE launch (csrc/ffn_fused.hip);
+            # the packed operands are what the backward launch multiplies by (valid until the next forward, like every step pack)
+            w1p, w2p = pack_kc_cached(w1, fresh), pack_kc_cached(w2, fresh)
+            h = torch.empty((hid,) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
+            z, y = torch.empty_like(h), torch.empty_like(x)
+            check(_lib.load().advhip_ffn_block_fwd_f32(ptr(x), ptr(gf), ptr(bf), C.c_float(eps), ptr(w1.detach()), ptr(b1.detach()), ptr(w2.detach()),
+                                                       ptr(b2.detach()), ptr(xh), ptr(mu), ptr(rs), ptr(h), ptr(z), ptr(y), c, n, stream(x)), "ffn_block_fwd")
+            ctx.save_for_backward(x, gf, mu, rs, xh, z, h, w1p, w2p)
+            ctx.params = (w1, b1, w2, b2)
+            ctx.ln_params = (g, b)
+            ctx.eps, ctx.gshape = eps, g.shape
+            return y
         check(_lib.load().advhip_chan_layernorm_fwd_f32(ptr(x), ptr(gf), ptr(bf), ptr(xh), ptr(mu), ptr(rs), c, n, C.c_float(eps), stream(x)),
               "chan_layernorm_fwd")
         h, z = conv_cn(xh, pack_kc_cached(w1, fresh), hid, 1, shift=b1.detach(), act=ACT_GELU_D, want_preact=True)  # z = GELU'(pre-activation)
@@ -661,11 +675,25 @@ class _FFNBlockCN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, gf, mu, rs, xh, z, h, w1, w2 = ctx.saved_tensors
-        hid, dim = w1.shape[0], w1.shape[1]
+        hid, dim = z.shape[0], x.shape[0]
         n = x.numel() // dim
         need = ctx.needs_input_grad
         dy = dy.contiguous()
         w1p, b1p, w2p, b2p = ctx.params
+        if ctx.fused:  # (w1 / w2 of the saved tensors are the PACKED operands here: [C][4C] and [4C][C])
+            lib = _lib.load()
+            rows = lib.advhip_ffn_block_partial_rows(n)
+            dz, dx = torch.empty_like(z), torch.empty_like(x)
+            pgb = torch.empty((rows, 2 * dim), device=x.device, dtype=torch.float32)
+            check(lib.advhip_ffn_block_bwd_f32(ptr(dy), ptr(x), ptr(gf), ptr(mu), ptr(rs), C.c_float(ctx.eps), ptr(z), ptr(w2), ptr(w1), ptr(dz), ptr(dx),
+                                               ptr(pgb), dim, n, stream(x)), "ffn_block_bwd")
+            dw2, db2 = _dw_db(dy, h, need[6], need[7], w2p, b2p)
+            dw1, db1 = _dw_db(dz, xh, need[4], need[5], w1p, b1p)
+            gp, bp = ctx.ln_params
+            if need[1] and need[2] and _defer_colsum(pgb, [(gp, 0, dim), (bp, dim, 2 * dim)]):
+                return dx, None, None, None, dw1, db1, dw2, db2, None
+            sums = colsum(pgb)
+            return dx, sums[:dim].reshape(ctx.gshape), sums[dim:].reshape(ctx.gshape), None, dw1, db1, dw2, db2, None
         dw2, db2 = _dw_db(dy, h, need[6], need[7], w2p, b2p)
         dz = conv_cn(dy, w2.detach().view(dim, hid), hid, 1, dact_z=z, act=ACT_MUL)  # (W2^T dY) * GELU'(pre-activation), saved by the forward
         dw1, db1 = _dw_db(dz, xh, need[4], need[5], w1p, b1p)
@@ -681,6 +709,18 @@ class _FFNBlockCN(torch.autograd.Function):
             return dx, None, None, None, dw1, db1, dw2, db2, None
         sums = colsum(pgb)
         return dx, sums[:dim].reshape(ctx.gshape), sums[dim:].reshape(ctx.gshape), None, dw1, db1, dw2, db2, None
+
+
+# ADV_MGFN_FUSED_FFN=1 (opt-in): the narrow blocks' `x + FFN(LN(x))` step as ONE launch forward and one backward (csrc/ffn_fused.hip) instead of
+# three + three.  Measured inside the graph-replayed training step (profiles/r06_studies.md section 7): 64 channels 26.5 + 29.0 us against
+# 37 + 29, 128 channels 74 + 99 us against 52 + 46 -- the step as a whole 15.1 ms with it, 14.8 without on the same box.  Off by default.
+FUSED_FFN = os.environ.get("ADV_MGFN_FUSED_FFN", "0") == "1"
+
+
+def fused_ffn_ok(c: int, hid: int, n: int, w1: torch.Tensor, w2: torch.Tensor) -> bool:
+    """advhip_ffn_block_fwd/bwd_f32's shape rules: 64 or 128 channels, hidden = 4 x, a multiple of 64 positions, weights as stored."""
+    return (FUSED_FFN and c in (64, 128) and hid == 4 * c and n % 64 == 0 and tuple(w1.shape[:2]) == (hid, c) and tuple(w2.shape[:2]) == (c, hid)
+            and w1.is_contiguous() and w2.is_contiguous())
 
 
 PENDING_COUNTERS: list = []  # BatchNorm1d.num_batches_tracked tensors whose += 1 is still owed

@@ -404,6 +404,24 @@ int advhip_bn_rows_bwd_add_f32(const float* dy, const float* x, const float* gam
 int advhip_chan_layernorm_bwd_add_f32(const float* dy, const float* x, const float* g, const float* mu, const float* rs,
                                       const float* add, float* dx, float* dgb_partial, int32_t C, int64_t N, float eps, void* stream);
 
+/* A whole `x = x + FFN(LN(x))` step of a NARROW block in one launch (MGFNLayerNorm -> Conv1d(C, 4C, 1) -> GELU -> Conv1d(4C, C, 1) -> + x,
+ * modeling_mgfn.py:36-64, 147, 205), C = 64 or 128 channels, N a multiple of 64 positions, activations (C, N) with the positions contiguous:
+ *   forward : w1 = in_conv.weight (4C, C), w2 = out_conv.weight (C, 4C) AS STORED; writes y and what the backward pass keeps: xh = LN(x),
+ *             mu / rs (N), h = GELU(W1 xh + b1) and z = GELU'(W1 xh + b1), both (4C, N);
+ *   backward: w2_packed / w1_packed = the forward GEMMs' packed operands [4C][C] / [C][4C] (advhip_conv3d_pack_weight_f32); writes
+ *             dz = (W2^T dy) * z (4C, N) -- what the weight gradients dW1 = dz xh^T, db1 = rowsum(dz) contract with (dW2 = dy h^T) --,
+ *             dx = LayerNorm backward of W1^T dz + dy (the skip connection), and dgb_partial [advhip_ffn_block_partial_rows(N)][2C]: per-workgroup
+ *             partial sums of dg (columns [0, C)) and db ([C, 2C)), to be column-summed (advhip_colsum_f32 / _group).
+ * The same arithmetic as advhip_chan_layernorm_fwd_f32 + two advhip_conv3d_bn_act_ex_f32 launches (activation code 3, then bias + residual) and
+ * their three backward launches; sums inside a dot product run in another order (agreement ~1e-6). */
+int64_t advhip_ffn_block_partial_rows(int64_t N);
+int advhip_ffn_block_fwd_f32(const float* x, const float* ln_g, const float* ln_b, float eps, const float* w1, const float* b1,
+                             const float* w2, const float* b2, float* xh, float* mu, float* rs, float* h, float* z, float* y, int32_t C,
+                             int64_t N, void* stream);
+int advhip_ffn_block_bwd_f32(const float* dy, const float* x, const float* ln_g, const float* mu, const float* rs, float eps, const float* z,
+                             const float* w2_packed, const float* w1_packed, float* dz, float* dx, float* dgb_partial, int32_t C, int64_t N,
+                             void* stream);
+
 /* The packed operand of a Conv1d's transposed conv (its input gradient dX = conv1d(dY; W'), W'[c][o][j] = W[o][c][k-1-j];
  * autograd of nn.Conv1d, modeling_mgfn.py:101,155) straight from the parameter w (Cout, Cin, k):
  * w_packed[(o*k + j)][c] = w[o][c][k-1-j], rows padded with zeros to a multiple of 32 -- one launch instead of flip +

@@ -614,3 +614,48 @@ def test_amp_combine_matches_torch_forward_and_backward():
     yr.backward(gy.double())
     for g, w in zip(got, [yr.detach(), zd.grad, bias.grad, wm.grad, bm.grad]):
         assert g.shape == w.shape and rel_err(g.cpu().double(), w.cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("c,b,t", [(64, 320, 32), (128, 320, 32), (64, 6, 32), (128, 2, 32)])
+def test_fused_narrow_ffn_block_equals_the_three_launch_form_and_fp64(c, b, t, monkeypatch):
+    """advhip_ffn_block_fwd/bwd_f32 (csrc/ffn_fused.hip): `x + FFN(LN(x))` of a 64- / 128-channel block as one launch forward and one backward
+    (MGFNLayerNorm -> Conv1d -> GELU -> Conv1d -> + x, modeling_mgfn.py:36-64, 147, 205) against fp64 autograd of the same formulas and
+    against the three-launch form it replaces: y, dx and all six parameter gradients."""
+    from anomaly_detection_on_video_amd import mgfn_ops
+    from anomaly_detection_on_video_amd.models.mgfn.modeling_mgfn import MGFNFeedForward
+
+    torch.manual_seed(c + b)
+    ffn = MGFNFeedForward(c).to(DEV)
+    with torch.no_grad():
+        ffn.layer_norm.g.add_(torch.randn_like(ffn.layer_norm.g) * 0.3)
+        ffn.layer_norm.b.add_(torch.randn_like(ffn.layer_norm.b) * 0.3)
+    x = synth_tensor(f"ffnf.x{c}{b}", (c, b, t), scale=2.0).to(DEV).requires_grad_(True)
+    gy = synth_tensor(f"ffnf.g{c}{b}", (c, b, t), scale=1.0).to(DEV)
+    params = list(ffn.parameters())
+    got = {}
+    for fused in (True, False):
+        monkeypatch.setattr(mgfn_ops, "FUSED_FFN", fused)
+        assert mgfn_ops.fused_ffn_ok(c, 4 * c, b * t, ffn.in_conv.weight, ffn.out_conv.weight) == fused
+        for p in params + [x]:
+            p.grad = None
+        y = mgfn_ops.ffn_block_cn(x, ffn.layer_norm, ffn.in_conv, ffn.out_conv)
+        y.backward(gy)
+        got[fused] = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in params]
+    # fp64 reference (the reference module's formulas)
+    xd = x.detach().double().cpu().requires_grad_(True)
+    g, bb = ffn.layer_norm.g.detach().double().cpu().requires_grad_(True), ffn.layer_norm.b.detach().double().cpu().requires_grad_(True)
+    w1, b1 = ffn.in_conv.weight.detach().double().cpu().requires_grad_(True), ffn.in_conv.bias.detach().double().cpu().requires_grad_(True)
+    w2, b2 = ffn.out_conv.weight.detach().double().cpu().requires_grad_(True), ffn.out_conv.bias.detach().double().cpu().requires_grad_(True)
+    xb = xd.permute(1, 0, 2)  # (b, c, t)
+    mean = xb.mean(dim=1, keepdim=True)
+    var = xb.var(dim=1, unbiased=False, keepdim=True)
+    xh = (xb - mean) / (var.sqrt() + ffn.layer_norm.eps) * g.view(1, -1, 1) + bb.view(1, -1, 1)
+    hh = torch.nn.functional.gelu(torch.nn.functional.conv1d(xh, w1, b1))
+    yr = (torch.nn.functional.conv1d(hh, w2, b2) + xb).permute(1, 0, 2)
+    yr.backward(gy.double().cpu())
+    # parameter order of MGFNFeedForward: layer_norm.g, layer_norm.b, in_conv.weight, in_conv.bias, out_conv.weight, out_conv.bias
+    ref = [yr.detach(), xd.grad, g.grad.reshape(ffn.layer_norm.g.shape), bb.grad.reshape(ffn.layer_norm.b.shape), w1.grad, b1.grad, w2.grad, b2.grad]
+    assert [tuple(p.shape) for p in params] == [tuple(r.shape) for r in ref[2:]]
+    for name, a, u, r in zip(["y", "dx", "dg", "db", "dW1", "db1", "dW2", "db2"], got[True], got[False], ref):
+        assert rel_err(a.cpu(), r) < 2e-5, name
+        assert rel_err(a.cpu(), u.cpu()) < 2e-5, name
