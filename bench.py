@@ -257,7 +257,8 @@ def dry_run(args, clips, rank: int, world: int):
             "config": {"local_batch": args.batch, "global_batch": gb, "clips_per_video": "U[50,500] seeded", "stream_start": pos0,
                        "videos_scored_all_ranks": int(n_scored.item()), "videos_scored_rank0_timed": len(scored) - before,
                        "backend": torch.distributed.get_backend() if world > 1 else "none (single process)",
-                       "world_size_observed": torch.distributed.get_world_size() if world > 1 else 1}}
+                       "world_size_observed": torch.distributed.get_world_size() if world > 1 else 1,
+                       **({"env": comm_env()} if world > 1 else {})}}
 
 
 def main():

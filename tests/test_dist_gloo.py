@@ -165,3 +165,5 @@ def test_bench_launches_eight_ranks_dry():
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and out["steps"] == 20 and out["warmup"] == 5 and out["dry_run"] is True
+    # the N > 1 line says what environment its ranks talked under (bench.launch_ranks sets both for the processes it starts)
+    assert out["config"]["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0" and out["config"]["env"].get("NCCL_DEBUG") == "WARN"
