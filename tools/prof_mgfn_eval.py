@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Dev tool: N whole-video scoring passes (the validation forward, (1, 10, T, 2049), eval) for rocprofv3; prints wall ms per pass alone.
-    python tools/prof_mgfn_eval.py [T=290] [N=20]"""
+    python tools/prof_mgfn_eval.py [T=290] [N=20] [graph]      (graph: the pass captured once as a HIP graph and replayed -- what a graph per
+                                                                video length, pipeline.ExtractScoreStream's ADV_SCORE_GRAPH=1, runs)"""
 import os
 import sys
 import time
@@ -27,3 +28,17 @@ with torch.no_grad():
         m(video=v)
     torch.cuda.synchronize()
 print(f"eval (1,10,{T},2049): {(time.perf_counter() - t) / n * 1e3:.3f} ms per pass alone")
+if len(sys.argv) > 3 and sys.argv[3] == "graph":
+    with torch.no_grad():
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = m(video=v).scores
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            g.replay()
+        torch.cuda.synchronize()
+    print(f"eval (1,10,{T},2049): {(time.perf_counter() - t) / n * 1e3:.3f} ms per pass as one HIP-graph replay")
